@@ -1,0 +1,175 @@
+/* spsp.h -- C ABI of libspsp.so: the MI355X (gfx950) hot path of SoccerPlayerShapePose.
+ *
+ *   proxy crop [18,256,256] -> ResNet-18 + IEF -> (cam, pose6d, betas) -> rot6d -> R[24,3,3]
+ *   -> per-player 2D-reprojection fit (analytic gradient + Adam, all iterations in one launch)
+ *   -> SMPL forward (blend shapes + 24-joint LBS) -> vertices [6890,3], joints [90,3]
+ *
+ * The reference has no FFI: its boundary is a set of Python callables.  Each entry
+ * point below names the reference callable it replaces; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch) unless it is marked
+ *     "host"; the library never allocates or frees caller-visible memory.
+ *   - all fp32 tensors are dense row-major with the shapes given; R is [B,24,3,3] row-major with
+ *     joint 0 = global orientation, joints 1..23 = body pose (smplx full_pose order).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) and performs no host synchronisation.
+ *   - return value: SPSP_OK or a negative status; spsp_last_error() gives a thread-local message.
+ *   - opaque handles are immutable after load; a handle's internal workspace serves ONE call in
+ *     flight at a time (enqueue calls that share a handle on one stream, or load one handle per stream).
+ */
+#ifndef SPSP_H
+#define SPSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPSP_OK       0
+#define SPSP_EINVAL  (-1)
+#define SPSP_ENOMEM  (-2)
+#define SPSP_EHIP    (-3)
+#define SPSP_ENCCL   (-4)
+
+#define SPSP_NUM_VERTS      6890
+#define SPSP_NUM_JOINTS     24
+#define SPSP_NUM_BETAS      10
+#define SPSP_NUM_POSE_BASIS 207
+#define SPSP_NUM_OUT_JOINTS 90   /* 24 chain + 21 picked vertices + 9 extra + 19 cocoplus + 17 h36m */
+#define SPSP_NUM_FIT_JOINTS 17   /* PR/config.py:38 SMPL_TO_KPRCNN_MAP */
+#define SPSP_RECORD_FLOATS  229  /* [cam(3) | R(24*9) | betas(10)] -- the all-gather record, SURVEY 8e */
+#define SPSP_NUM_CONVS      20   /* convs of resnet18(in_channels=18), order of spsp_conv_name() */
+#define SPSP_PROXY_C        18
+#define SPSP_PROXY_WH       256
+#define SPSP_PROXY_PAD      3    /* zero border of the backbone-native input layout */
+
+typedef struct spsp_ctx       spsp_ctx;
+typedef struct spsp_regressor spsp_regressor;
+typedef struct spsp_smpl      spsp_smpl;
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* Binds the calling thread to HIP device `device` and creates the context. */
+int         spsp_init(int device, spsp_ctx** out);
+void        spsp_destroy(spsp_ctx* ctx);
+const char* spsp_last_error(void);
+const char* spsp_version(void);
+
+/* ---- regressor: replaces SingleInputRegressor (PR/models/regressor.py:13-48) ------------------ */
+typedef struct {
+    const float* weight;        /* host [cout,cin,k,k] fp32 (torch Conv2d layout), no bias (resnet.py:30-36) */
+    const float* bn_weight;     /* host [cout] */
+    const float* bn_bias;       /* host [cout] */
+    const float* bn_mean;       /* host [cout] running_mean */
+    const float* bn_var;        /* host [cout] running_var  */
+} spsp_conv_bn;
+
+typedef struct {
+    spsp_conv_bn conv[SPSP_NUM_CONVS]; /* eval-mode BN is folded into the conv at load (eps 1e-5) */
+    const float* fc_weight[3];         /* host fc1 [512,669], fc2 [512,512], fc3 [157,512] (ief_module.py:16-18) */
+    const float* fc_bias[3];           /* host [512], [512], [157] */
+    const float* init_params;          /* host [157] = [0.9,0,0 | mean pose6d(144) | mean shape(10)] (ief_module.py:33-46) */
+    int          ief_iters;            /* 3 (regressor.py:31-34) */
+} spsp_regressor_weights;
+
+/* State-dict prefix of conv i (e.g. "image_encoder.layer2.0.downsample.0"); NULL when out of range. */
+const char* spsp_conv_name(int i);
+/* State-dict prefix of the BatchNorm that follows conv i. */
+const char* spsp_conv_bn_name(int i);
+
+/* precision: 0 = bf16 MFMA (bf16 weights/activations, fp32 accumulate);
+ *            1 = split-bf16 x3 MFMA (hi+lo planes, ~fp32-accurate; 3x the MFMA work). */
+int  spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_batch, int precision,
+                         spsp_regressor** out);
+void spsp_regressor_free(spsp_regressor* r);
+
+#define SPSP_PROXY_NCHW_F32   0  /* [B,18,256,256] fp32 -- what the reference feeds (predict_3D.py:126) */
+#define SPSP_PROXY_NATIVE     1  /* [B,262,262,18] bf16 NHWC with a 3-px ZERO border (caller keeps it zero) */
+
+/* Bytes of one crop in the native layout. */
+size_t spsp_proxy_native_bytes(void);
+/* NCHW fp32 -> native layout (writes interior AND border). */
+int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_out, void* stream);
+
+/* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
+int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
+                           float* cam, float* pose6d, float* betas, float* feats, void* stream);
+/* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
+ * (0 conv1+relu, 1 maxpool, 2..5 layer1..layer4) of the LAST forward as fp32 NCHW into `out`. */
+int spsp_regressor_read_stage(spsp_ctx* ctx, spsp_regressor* r, int stage, int B, float* out_nchw, void* stream);
+
+/* ---- small geometry ops ---------------------------------------------------------------------- */
+/* rot6d_to_rotmat (PR/utils/rigid_transform_utils.py:27-41): pose6d [n,6] -> R [n,3,3]. */
+int spsp_rot6d_to_rotmat(spsp_ctx* ctx, const float* pose6d, int n, float* R, void* stream);
+/* orthographic_project_torch + undo_keypoint_normalisation (PR/utils/cam_utils.py:5-26,
+ * PR/utils/joints2d_utils.py:5-10): pts [B,n,3], cam [B,3] -> out [B,n,2].
+ * img_wh > 0: pixels (uv+1)*img_wh/2;  img_wh == 0: normalised uv. */
+int spsp_project(spsp_ctx* ctx, const float* pts, const float* cam, int B, int n, float img_wh,
+                 float* out, void* stream);
+/* convert_weak_perspective_to_camera_translation_torch (PR/utils/cam_utils.py:28-34). */
+int spsp_wp_to_translation(spsp_ctx* ctx, const float* cam, int B, float focal, float resolution,
+                           float* translation, void* stream);
+/* [cam | R | betas] -> record [B,229] and back (the RCCL all-gather payload). */
+int spsp_pack_record(spsp_ctx* ctx, const float* cam, const float* R, const float* betas, int B,
+                     float* record, void* stream);
+int spsp_unpack_record(spsp_ctx* ctx, const float* record, int B, float* cam, float* R, float* betas,
+                       void* stream);
+
+/* ---- SMPL: replaces SMPL.forward (PR/models/smpl_official.py:27-41 -> smplx.lbs.lbs) ---------- */
+typedef struct {
+    const float*   v_template;          /* host [6890,3] */
+    const float*   shapedirs;           /* host [6890,3,10] */
+    const float*   posedirs;            /* host [207,20670] (smplx layout) */
+    const float*   J_regressor;         /* host [24,6890] dense */
+    const float*   lbs_weights;         /* host [6890,24] */
+    const int32_t* parents;             /* host [24], parents[0] = -1 */
+    const int32_t* vertex_joint_ids;    /* host [21] VertexJointSelector ids */
+    const float*   J_regressor_extra;   /* host [9,6890]  (smpl_official.py:17) */
+    const float*   J_regressor_cocoplus;/* host [19,6890] (smpl_official.py:18) */
+    const float*   J_regressor_h36m;    /* host [17,6890] (smpl_official.py:19) */
+} spsp_smpl_arrays;
+
+int  spsp_smpl_load(spsp_ctx* ctx, const spsp_smpl_arrays* a, int max_batch, spsp_smpl** out);
+void spsp_smpl_free(spsp_smpl* s);
+
+/* R [B,24,9], betas [B,10] -> verts [B,6890,3] (NULL to skip), joints [B,90,3] (NULL to skip). */
+int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B,
+                      float* verts, float* joints, void* stream);
+
+/* ---- fit: replaces optimize_camera (PR/PyTorch3DTest.py:3055-3124) and the fit body of
+ *      single_view_optimization (PR/player_recon.py:1172-1294) -------------------------------- */
+#define SPSP_FIT_GLOBAL_ORIENT  (1u << 0)           /* joint 0 */
+#define SPSP_FIT_BODY_JOINT(k)  (1u << (k))          /* SMPL joint k = 1..23 (body_pose index k-1) */
+#define SPSP_FIT_CAM            (1u << 24)
+#define SPSP_FIT_BETAS          (1u << 25)
+/* variant A: {cam, global_orient};  variant B: + body_pose idx {0-5, 8-20} = joints {1-6, 9-21} + betas */
+#define SPSP_FIT_MASK_CAMERA    (SPSP_FIT_GLOBAL_ORIENT | SPSP_FIT_CAM)
+#define SPSP_FIT_MASK_POSE_SHAPE (SPSP_FIT_GLOBAL_ORIENT | SPSP_FIT_CAM | SPSP_FIT_BETAS | 0x003FFE7Eu)
+
+#define SPSP_FIT_SELECT_LAST     0  /* what optimize_camera leaves in place */
+#define SPSP_FIT_SELECT_BEST_L2E 1  /* lowest joints2D_l2es iterate (ties -> later iterate) */
+
+typedef struct {
+    int      iters;        /* 50 */
+    double   lr;           /* 0.01 (A) / 1e-3 (B); doubles because torch derives the step size in Python floats */
+    double   beta1, beta2, eps;  /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+    double   loss_weight;  /* 1.0 -> log_var = -ln(w + 1e-6) (multi_task_loss.py:37-38) */
+    uint32_t param_mask;   /* SPSP_FIT_* bits */
+    float    img_wh;       /* 512: pixel space of joints2D / projections (S/global_var.py:32) */
+    float    loss_wh;      /* 256: divisor used by the loss normalisation (multi_task_loss.py:106-107) */
+    int      select_mode;  /* SPSP_FIT_SELECT_* */
+} spsp_fit_config;
+
+void spsp_fit_config_default(spsp_fit_config* c, int variant /* 0 = A camera, 1 = B pose+shape */);
+
+/* In place on R [B,24,9], betas [B,10], cam [B,3]; joints2d [B,17,2] pixels (img_wh space).
+ * loss_hist / l2e_hist: optional [B,iters] (value BEFORE the step of each iteration), NULL to skip. */
+int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
+             const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPSP_H */

@@ -1,0 +1,76 @@
+// Shared host-side plumbing for libspsp.so (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/spsp.h"
+
+namespace spsp {
+
+void set_error(const char* fmt, ...);
+
+#define SPSP_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            spsp::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return SPSP_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+#define SPSP_REQUIRE(cond, ...)                                                           \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            spsp::set_error(__VA_ARGS__);                                                 \
+            return SPSP_EINVAL;                                                           \
+        }                                                                                 \
+    } while (0)
+
+// Device allocations owned by a handle; freed together.
+struct DevicePool {
+    std::vector<void*> ptrs;
+    ~DevicePool() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    int alloc(T** out, size_t count, bool zero = false) {
+        void* p = nullptr;
+        SPSP_HIP_CHECK(hipMalloc(&p, count * sizeof(T) + 256));
+        if (zero) SPSP_HIP_CHECK(hipMemset(p, 0, count * sizeof(T) + 256));
+        ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return SPSP_OK;
+    }
+    template <typename T>
+    int upload(T** out, const T* host, size_t count) {
+        int rc = alloc(out, count);
+        if (rc != SPSP_OK) return rc;
+        SPSP_HIP_CHECK(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+        return SPSP_OK;
+    }
+};
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+// float -> bf16 bits, round-to-nearest-even (host side; finite inputs).
+inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFF) ? 0x40 : 0));
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32_host(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace spsp
+
+struct spsp_ctx {
+    int device;
+    int num_cus;
+};

@@ -1,0 +1,382 @@
+// The per-player reprojection fit as a sequence of lane-parallel PHASES over one LDS-resident state.
+//
+// Replaces the reference's per-player Adam loops (optimize_camera PR/PyTorch3DTest.py:3055-3124;
+// single_view_optimization PR/player_recon.py:1172-1294; census in SURVEY Appendix E): instead of a full
+// 6890-vertex SMPL.forward + autograd per iteration it evaluates only what the joints2D loss touches
+// (24 chain joints + 5 face vertices), with a hand-derived reverse sweep over the
+// kinematic tree and torch-default Adam, ALL iterations inside one launch, one wavefront per player.
+//
+// A phase is a pure function of (lane, shared state): it reads LDS written by earlier phases and writes
+// disjoint LDS slots; a barrier separates consecutive phases.  No cross-lane register traffic is used
+// (reductions go through LDS partials), so the very same code runs
+//   * on the GPU   (fit.hip: 64 lanes = one wavefront, barrier = single-wave s_barrier), and
+//   * on the host  (tests/emul: `for lane in 0..63` per phase) -- a CPU check of the kernel's index math.
+//
+// Reverse sweep (Appendix D).  With W_k = (Rw_k, tw_k) the world transform of joint k, p = parent(k):
+//   direct adjoints  a_k = dL/d tw_k = g_k + sum_v w_vk h_v,   B_k = dL/d Rw_k = sum_v w_vk h_v (vp_v - J_k)^T
+//   leaves -> root   abar_p += abar_c,   Bbar_p += abar_c (J_c - J_p)^T + Bbar_c R_c^T
+//   parameters       dL/dR_k = Rw_p^T Bbar_k (k>0), dL/dG = Bbar_0,  dL/dR_k[e] += sum_c P5[(k-1)*9+e][c] dvp[c]
+//                    dL/dJ_k = -sum_v w_vk Rw_k^T h_v + Rw_p^T abar_k (k>0; abar_0 for the root) - Rw_k^T (abar_k - a_k)
+//                    dL/dvp_v = sum_k w_vk Rw_k^T h_v,   dL/dbeta = S5^T dvp + JS^T dJ
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "smpl_consts.hpp"
+
+#if defined(__HIPCC__)
+#define SPSP_HD __host__ __device__ __forceinline__
+#else
+#define SPSP_HD inline
+#endif
+
+namespace spsp {
+
+constexpr int kNumPrm = SPSP_RECORD_FLOATS;   // 229: [cam(3) | R(216) | betas(10)]
+constexpr int kPrmR = 3, kPrmBeta = 219;
+
+// fit joint i reads output joint kFitSrc[i] (PR/config.py:38); < 24: chain joint, >= 24: face vertex (idx-24)
+#define SPSP_FIT_SRC {24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7, 8}
+// inverse maps: chain joint k -> fit joint (or -1); face vertex v -> fit joint
+#define SPSP_FIT_OF_JOINT {-1, 11, 12, -1, 13, 14, -1, 15, 16, -1, -1, -1, -1, -1, -1, -1, 5, 6, 7, 8, 9, 10, -1, -1}
+#define SPSP_FIT_OF_FACE {0, 2, 1, 4, 3}
+
+struct FitParams {           // kernel arguments (plain data)
+    int iters;
+    double lr, beta1, beta2, eps;
+    uint32_t param_mask;
+    float img_wh, loss_wh;
+    float log_var, weight;   // lv = -ln(loss_weight + 1e-6) as fp32, w = exp(-lv)
+    int select_mode;
+    int num_levels;
+};
+
+struct FitShared {
+    float fc[kFcTotal];
+    float prm[232];
+    float best[232];
+    float grad[232];
+    float J[72];
+    float W[288];
+    float vp[16];
+    float xf[16];
+    float part[64];
+    float part2[64];
+    float g[34];
+    float rpart[17 * 5];     // per-fit-joint partials: loss, l2e, gs, gtx, gty
+    float red[8];            // reduced: loss, l2e, gs, gtx, gty
+    float adir[72], abar[72], Bbar[216];
+    float dvp[16], dJ[72], dJt[72];
+    float tgt_px[34];
+    float best_l2e;
+    int take_best;
+    int parents[24], level_joints[24], level_start[26], child_start[25], child_list[24];
+};
+
+struct FitLane {             // per-lane registers that live across iterations
+    float m[4], v[4];
+};
+
+SPSP_HD bool fit_trainable(uint32_t mask, int p) {
+    if (p < kPrmR) return (mask >> 24) & 1u;
+    if (p < kPrmBeta) return (mask >> ((p - kPrmR) / 9)) & 1u;
+    return (mask >> 25) & 1u;
+}
+
+// ---- one-time set-up -----------------------------------------------------------------------------------
+SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, const int* parents,
+                      const int* level_joints, const int* level_start, const int* child_start,
+                      const int* child_list, const float* R, const float* betas, const float* cam,
+                      const float* joints2d) {
+    for (int i = lane; i < kFcTotal; i += 64) s.fc[i] = fitc[i];
+    for (int p = lane; p < 232; p += 64) {
+        float v = 0.f;
+        if (p < kPrmR) v = cam[p];
+        else if (p < kPrmBeta) v = R[p - kPrmR];
+        else if (p < kNumPrm) v = betas[p - kPrmBeta];
+        s.prm[p] = v;
+        s.best[p] = v;
+        s.grad[p] = 0.f;
+    }
+    if (lane < 34) s.tgt_px[lane] = joints2d[lane];
+    if (lane < 24) {
+        s.parents[lane] = parents[lane];
+        s.level_joints[lane] = level_joints[lane];
+        s.child_list[lane] = child_list[lane];
+    }
+    if (lane < 26) s.level_start[lane] = level_start[lane];
+    if (lane < 25) s.child_start[lane] = child_start[lane];
+    if (lane == 0) { s.best_l2e = INFINITY; s.take_best = 0; }
+    for (int q = 0; q < 4; ++q) r.m[q] = r.v[q] = 0.f;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------
+// P1: J = Jbar + JS.beta (72 items); partial sums of the 5 posed face vertices over 4 chunks of the 207 pose
+//     features (+ template + shape term in chunk 0).  lane = q*16 + c, c = v*3+i < 15.
+SPSP_HD void fit_p1(FitShared& s, int lane) {
+    const float* beta = s.prm + kPrmBeta;
+    for (int o = lane; o < 72; o += 64) {
+        float acc = s.fc[kFcJbar + o];
+        for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcJS + i * 72 + o], beta[i], acc);
+        s.J[o] = acc;
+    }
+    const int q = lane >> 4, c = lane & 15;
+    float acc = 0.f;
+    if (c < 15) {
+        if (q == 0) {
+            acc = s.fc[kFcVt5 + c];
+            for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcS5 + i * 16 + c], beta[i], acc);
+        }
+        const int j0 = q * 52, j1 = (j0 + 52 < kNP) ? j0 + 52 : kNP;
+        for (int j = j0; j < j1; ++j) {
+            const int e = j % 9;
+            const float f = s.prm[kPrmR + 9 + j] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            acc = fmaf(s.fc[kFcP5 + j * 16 + c], f, acc);
+        }
+    }
+    s.part[lane] = acc;
+}
+
+// P2: finish vp; root transform W_0 = [G | J_0].
+SPSP_HD void fit_p2(FitShared& s, int lane) {
+    if (lane < 15) s.vp[lane] = (s.part[lane] + s.part[16 + lane]) + (s.part[32 + lane] + s.part[48 + lane]);
+    if (lane >= 16 && lane < 28) {
+        const int e = lane - 16, i = e >> 2, c = e & 3;
+        s.W[e] = (c < 3) ? s.prm[kPrmR + i * 3 + c] : s.J[i];
+    }
+}
+
+// P3[l]: kinematic chain, level l >= 1: W_k = W_p * [R_k | J_k - J_p]; 5 joints x 12 elements per pass.
+SPSP_HD void fit_chain_level(FitShared& s, int lane, int l) {
+    const int slot = lane / 12, e = lane % 12, i = e >> 2, c = e & 3;
+    if (slot >= 5) return;
+    const float* Rm = s.prm + kPrmR;
+    for (int idx = s.level_start[l] + slot; idx < s.level_start[l + 1]; idx += 5) {
+        const int k = s.level_joints[idx], p = s.parents[k];
+        const float* Wp = s.W + p * 12 + i * 4;
+        float acc;
+        if (c < 3) {
+            acc = Wp[0] * Rm[k * 9 + c];
+            acc = fmaf(Wp[1], Rm[k * 9 + 3 + c], acc);
+            acc = fmaf(Wp[2], Rm[k * 9 + 6 + c], acc);
+        } else {
+            acc = Wp[0] * (s.J[k * 3] - s.J[p * 3]);
+            acc = fmaf(Wp[1], s.J[k * 3 + 1] - s.J[p * 3 + 1], acc);
+            acc = fmaf(Wp[2], s.J[k * 3 + 2] - s.J[p * 3 + 2], acc);
+            acc += Wp[3];
+        }
+        s.W[k * 12 + e] = acc;
+    }
+}
+
+// P4: face vertices x_v = sum_k w_vk (Rw_k (vp_v - J_k) + tw_k); lane = q*16 + (v*3+i), q = 6-joint chunk.
+SPSP_HD void fit_p4(FitShared& s, int lane) {
+    const int q = lane >> 4, o = lane & 15;
+    float acc = 0.f;
+    if (o < 15) {
+        const int v = o / 3, i = o % 3;
+        for (int k = q * 6; k < q * 6 + 6; ++k) {
+            const float* w = s.W + k * 12 + i * 4;
+            float t = fmaf(w[0], s.vp[v * 3] - s.J[k * 3],
+                           fmaf(w[1], s.vp[v * 3 + 1] - s.J[k * 3 + 1],
+                                fmaf(w[2], s.vp[v * 3 + 2] - s.J[k * 3 + 2], w[3])));
+            acc = fmaf(s.fc[kFcW5 + v * 24 + k], t, acc);
+        }
+    }
+    s.part[lane] = acc;
+}
+
+SPSP_HD void fit_p5(FitShared& s, int lane) {
+    if (lane < 15) s.xf[lane] = (s.part[lane] + s.part[16 + lane]) + (s.part[32 + lane] + s.part[48 + lane]);
+}
+
+// P6: project the 17 fit joints, residuals, per-joint loss / l2e / camera-gradient partials, dL/dX.
+//     pixels = (s (X + t) + 1) * img_wh/2  (cam_utils.py:5-26, joints2d_utils.py:5-10);
+//     n = 2 px / loss_wh - 1 on both sides, L = mean(d^2) * w + lv  (multi_task_loss.py:97-113).
+SPSP_HD void fit_p6(FitShared& s, int lane, const FitParams& P) {
+    if (lane >= 17) return;
+    const int src_tab[17] = SPSP_FIT_SRC;
+    const int src = src_tab[lane];
+    float X[2];
+    if (src < 24) { X[0] = s.W[src * 12 + 3]; X[1] = s.W[src * 12 + 7]; }
+    else { X[0] = s.xf[(src - 24) * 3]; X[1] = s.xf[(src - 24) * 3 + 1]; }
+    const float sc = s.prm[0];
+    const float half = P.img_wh / 2.0f;
+    const float dn_du = (2.0f * half) / P.loss_wh;           // d n / d u
+    const float coef = (2.0f * P.weight) / 34.0f;            // d L / d n = coef * (n - n*)
+    float loss = 0.f, l2 = 0.f, gs = 0.f, gt[2];
+    for (int c = 0; c < 2; ++c) {
+        const float t = s.prm[1 + c];
+        const float u = sc * (X[c] + t);
+        const float px = (u + 1.f) * half;
+        const float y = s.tgt_px[lane * 2 + c];
+        const float n = (2.0f * px) / P.loss_wh - 1.0f;
+        const float ns = (2.0f * y) / P.loss_wh - 1.0f;
+        const float d = n - ns;
+        loss = fmaf(d, d, loss);
+        const float dp = px - y;
+        l2 = fmaf(dp, dp, l2);
+        const float gu = coef * d * dn_du;                   // dL/du
+        s.g[lane * 2 + c] = gu * sc;                         // dL/dX_c
+        gs = fmaf(gu, X[c] + t, gs);
+        gt[c] = gu * sc;
+    }
+    float* rp = s.rpart + lane * 5;
+    rp[0] = loss; rp[1] = sqrtf(l2); rp[2] = gs; rp[3] = gt[0]; rp[4] = gt[1];
+}
+
+// ---- backward ------------------------------------------------------------------------------------------
+SPSP_HD float fit_h(const FitShared& s, int v, int i) {      // adjoint of face vertex v, component i (z: 0)
+    const int of_face[5] = SPSP_FIT_OF_FACE;
+    return i < 2 ? s.g[of_face[v] * 2 + i] : 0.f;
+}
+
+// P7: reductions of P6 (lanes 0..4); direct adjoints a_k, B_k; dvp partials; direct dJ.
+SPSP_HD void fit_p7(FitShared& s, int lane) {
+    if (lane < 5) {
+        float acc = 0.f;
+        for (int i = 0; i < 17; ++i) acc += s.rpart[i * 5 + lane];
+        s.red[lane] = acc;
+    }
+    const int of_joint[24] = SPSP_FIT_OF_JOINT;
+    for (int it = lane; it < 72; it += 64) {                 // item (k, i)
+        const int k = it / 3, i = it % 3;
+        float a = (i < 2 && of_joint[k] >= 0) ? s.g[of_joint[k] * 2 + i] : 0.f;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int v = 0; v < 5; ++v) {
+            const float wh = s.fc[kFcW5 + v * 24 + k] * fit_h(s, v, i);
+            a += wh;
+            b0 = fmaf(wh, s.vp[v * 3] - s.J[k * 3], b0);
+            b1 = fmaf(wh, s.vp[v * 3 + 1] - s.J[k * 3 + 1], b1);
+            b2 = fmaf(wh, s.vp[v * 3 + 2] - s.J[k * 3 + 2], b2);
+        }
+        s.adir[it] = a;
+        s.abar[it] = a;
+        s.Bbar[k * 9 + i * 3] = b0; s.Bbar[k * 9 + i * 3 + 1] = b1; s.Bbar[k * 9 + i * 3 + 2] = b2;
+    }
+    {   // dvp[v][l] partial over 6 joints: sum_k w_vk sum_i Rw_k[i][l] h_v[i]
+        const int q = lane >> 4, o = lane & 15;
+        float acc = 0.f;
+        if (o < 15) {
+            const int v = o / 3, l = o % 3;
+            const float h0 = fit_h(s, v, 0), h1 = fit_h(s, v, 1);
+            for (int k = q * 6; k < q * 6 + 6; ++k)
+                acc = fmaf(s.fc[kFcW5 + v * 24 + k], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
+        }
+        s.part2[lane] = acc;
+    }
+    for (int it = lane; it < 72; it += 64) {                 // direct dJ[k][l] = -sum_v w_vk sum_i Rw_k[i][l] h_v[i]
+        const int k = it / 3, l = it % 3;
+        float acc = 0.f;
+        for (int v = 0; v < 5; ++v)
+            acc = fmaf(s.fc[kFcW5 + v * 24 + k], fmaf(s.W[k * 12 + l], fit_h(s, v, 0), s.W[k * 12 + 4 + l] * fit_h(s, v, 1)), acc);
+        s.dJ[it] = -acc;
+    }
+}
+
+// P8: finish dvp; lane 63 turns the reductions into loss / l2e, history and the best-iterate decision.
+SPSP_HD void fit_p8(FitShared& s, int lane, const FitParams& P, int it, float* loss_hist, float* l2e_hist) {
+    if (lane < 15) s.dvp[lane] = (s.part2[lane] + s.part2[16 + lane]) + (s.part2[32 + lane] + s.part2[48 + lane]);
+    if (lane == 63) {
+        const float loss = (s.red[0] / 34.0f) * P.weight + P.log_var;
+        const float l2e = s.red[1] / 17.0f;
+        if (loss_hist) loss_hist[it] = loss;
+        if (l2e_hist) l2e_hist[it] = l2e;
+        const int take = !(l2e > s.best_l2e);                // ties -> later iterate (tracker uses '>')
+        s.take_best = take;
+        if (take) s.best_l2e = l2e;
+    }
+}
+
+// P9[l]: reverse sweep -- every joint p of level l gathers from its children (level l+1, already final).
+SPSP_HD void fit_reverse_level(FitShared& s, int lane, int l) {
+    const int slot = lane / 12, e = lane % 12;
+    if (slot >= 5) return;
+    const float* Rm = s.prm + kPrmR;
+    for (int idx = s.level_start[l] + slot; idx < s.level_start[l + 1]; idx += 5) {
+        const int p = s.level_joints[idx];
+        if (e < 3) {
+            float acc = s.abar[p * 3 + e];
+            for (int ci = s.child_start[p]; ci < s.child_start[p + 1]; ++ci) acc += s.abar[s.child_list[ci] * 3 + e];
+            s.abar[p * 3 + e] = acc;
+        } else {
+            const int i = (e - 3) / 3, c = (e - 3) % 3;
+            float acc = s.Bbar[p * 9 + i * 3 + c];
+            for (int ci = s.child_start[p]; ci < s.child_start[p + 1]; ++ci) {
+                const int ch = s.child_list[ci];
+                acc = fmaf(s.abar[ch * 3 + i], s.J[ch * 3 + c] - s.J[p * 3 + c], acc);
+                const float* Bc = s.Bbar + ch * 9 + i * 3;
+                const float* Rc = Rm + ch * 9 + c * 3;     // row c of R_child:  (Bbar_c R_c^T)[i][c] = sum_m Bbar_c[i][m] R_c[c][m]
+                acc = fmaf(Bc[0], Rc[0], fmaf(Bc[1], Rc[1], fmaf(Bc[2], Rc[2], acc)));
+            }
+            s.Bbar[p * 9 + i * 3 + c] = acc;
+        }
+    }
+}
+
+// P10: rotation gradients (incl. the pose-blend-shape path through the face vertices) and total dJ.
+SPSP_HD void fit_p10(FitShared& s, int lane) {
+    for (int it = lane; it < 216; it += 64) {                // item (k, l, c): dR_k[l][c]
+        const int k = it / 9, e = it % 9, l = e / 3, c = e % 3;
+        float acc;
+        if (k == 0) acc = s.Bbar[e];
+        else {
+            const float* Wp = s.W + s.parents[k] * 12;
+            acc = Wp[l] * s.Bbar[k * 9 + c];
+            acc = fmaf(Wp[4 + l], s.Bbar[k * 9 + 3 + c], acc);
+            acc = fmaf(Wp[8 + l], s.Bbar[k * 9 + 6 + c], acc);
+            const float* P5 = s.fc + kFcP5 + ((k - 1) * 9 + e) * 16;
+            for (int o = 0; o < 15; ++o) acc = fmaf(P5[o], s.dvp[o], acc);
+        }
+        s.grad[kPrmR + it] = acc;
+    }
+    for (int it = lane; it < 72; it += 64) {                 // dJ_total[k][l]
+        const int k = it / 3, l = it % 3;
+        float acc = s.dJ[it];
+        if (k == 0) acc += s.abar[l];
+        else {
+            const float* Wp = s.W + s.parents[k] * 12;
+            acc = fmaf(Wp[l], s.abar[k * 3], fmaf(Wp[4 + l], s.abar[k * 3 + 1], fmaf(Wp[8 + l], s.abar[k * 3 + 2], acc)));
+        }
+        const float* Wk = s.W + k * 12;
+        const float c0 = s.abar[k * 3] - s.adir[k * 3], c1 = s.abar[k * 3 + 1] - s.adir[k * 3 + 1],
+                    c2 = s.abar[k * 3 + 2] - s.adir[k * 3 + 2];
+        acc -= fmaf(Wk[l], c0, fmaf(Wk[4 + l], c1, Wk[8 + l] * c2));
+        s.dJt[it] = acc;
+    }
+}
+
+// P11: d beta partials over 4 chunks of the concatenated adjoint [dvp(15) | dJt(72)]; lane = q*16 + i.
+SPSP_HD void fit_p11(FitShared& s, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    float acc = 0.f;
+    if (i < 10) {
+        for (int o = q * 22; o < q * 22 + 22 && o < 87; ++o)
+            acc = (o < 15) ? fmaf(s.fc[kFcS5 + i * 16 + o], s.dvp[o], acc)
+                           : fmaf(s.fc[kFcJS + i * 72 + (o - 15)], s.dJt[o - 15], acc);
+    }
+    s.part[lane] = acc;
+}
+
+// P12: best-iterate snapshot (pre-step parameters) and the torch.optim.Adam step (single-tensor path):
+//   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(1-b2^t) + eps; p += (-lr/(1-b1^t) * m) / denom
+SPSP_HD void fit_p12(FitShared& s, FitLane& r, int lane, const FitParams& P, float step_size, float bc2_sqrt) {
+    const float w1 = (float)(1.0 - P.beta1), b2 = (float)P.beta2, w2 = (float)(1.0 - P.beta2), eps = (float)P.eps;
+    for (int q = 0; q < 4; ++q) {
+        const int p = lane + 64 * q;
+        if (p >= kNumPrm) break;
+        const float cur = s.prm[p];
+        if (s.take_best) s.best[p] = cur;
+        if (!fit_trainable(P.param_mask, p)) continue;
+        float g;
+        if (p < kPrmR) g = s.red[2 + p];
+        else if (p < kPrmBeta) g = s.grad[p];
+        else { const int i = p - kPrmBeta; g = (s.part[i] + s.part[16 + i]) + (s.part[32 + i] + s.part[48 + i]); }
+        r.m[q] = r.m[q] + w1 * (g - r.m[q]);
+        r.v[q] = r.v[q] * b2 + (w2 * g) * g;
+        const float denom = sqrtf(r.v[q]) / bc2_sqrt + eps;
+        s.prm[p] = cur + ((-step_size) * r.m[q]) / denom;
+    }
+}
+
+}  // namespace spsp

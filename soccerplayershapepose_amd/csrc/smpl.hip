@@ -1,0 +1,226 @@
+// SMPL forward for gfx950: blend shapes + joint regression + kinematic chain + linear-blend skinning
+// + the 90-joint set of the reference wrapper.  Replaces SMPL.forward (PR/models/smpl_official.py:27-41
+// -> smplx.lbs.lbs [EXT]).  VALU fp32 on purpose: the contraction is [B<=32..256] x 217 -- far too thin
+// for MFMA; the kernel is bound by streaming the 17.9 MB blend basis (HBM / Infinity Cache).
+//
+//   chain kernel   one wavefront per player: coef = [betas | R[1:]-I], J = Jbar + JS.betas, level-parallel
+//                  kinematic chain in LDS, rel. transforms A[24][3x4], posed joints 0..23.
+//   skin kernel    one thread per vertex, PB players per workgroup kept in registers so every basis row is
+//                  read ONCE per PB players; coef and A staged in LDS (broadcast reads); joint-major
+//                  LBS weights for coalesced loads.
+//   joints kernel  21 picked vertices + 45 regressed joints (CSR of the dense regressor rows) from the
+//                  FINAL vertices, as the reference does (smpl_official.py:30-34).
+#include <algorithm>
+#include <cmath>
+
+#include "smpl.hpp"
+#include "smpl_device.hpp"
+#include "smpl_host.hpp"
+
+namespace {
+using namespace spsp;
+
+constexpr int kSkinThreads = 128;
+constexpr int kPB = 8;   // players per skin workgroup
+
+__global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ R, const float* __restrict__ betas,
+                                                        const float* __restrict__ jconst,
+                                                        const int* __restrict__ parents,
+                                                        const int* __restrict__ level_joints,
+                                                        const int* __restrict__ level_start, int num_levels,
+                                                        float* __restrict__ A_out, float* __restrict__ coef_out,
+                                                        float* __restrict__ joints_out) {
+    __shared__ float sR[216], sBeta[16], sJ[72], sW[288], sJc[792];
+    __shared__ TreeLds tree;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    load_tree(tree, parents, level_joints, level_start, num_levels, lane);
+    for (int i = lane; i < 216; i += 64) sR[i] = R[(size_t)b * 216 + i];
+    if (lane < 10) sBeta[lane] = betas[b * 10 + lane];
+    for (int i = lane; i < 792; i += 64) sJc[i] = jconst[i];
+    __syncthreads();
+    // blend coefficients: betas, then pose feature (R[1:] - I) flattened row-major (smplx lbs, pose2rot=False)
+    for (int i = lane; i < kNCoef; i += 64) {
+        float v;
+        if (i < 10) v = sBeta[i];
+        else {
+            int j = i - 10, e = j % 9;
+            v = sR[9 + j] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        }
+        coef_out[(size_t)b * kNCoef + i] = v;
+    }
+    joints_from_betas(sJc, sJc + 72, sBeta, sJ, lane);
+    __syncthreads();
+    chain_forward(sR, sJ, sW, tree, lane);
+    // A_k = [W_k.R | W_k.t - W_k.R J_k]; posed joint k = W_k.t
+    for (int o = lane; o < 72; o += 64) {
+        int k = o / 3, i = o % 3;
+        const float* w = sW + k * 12 + i * 4;
+        float t = w[3] - (w[0] * sJ[k * 3] + w[1] * sJ[k * 3 + 1] + w[2] * sJ[k * 3 + 2]);
+        float* a = A_out + ((size_t)b * 24 + k) * 12 + i * 4;
+        a[0] = w[0]; a[1] = w[1]; a[2] = w[2]; a[3] = t;
+        if (joints_out) joints_out[((size_t)b * SPSP_NUM_OUT_JOINTS + k) * 3 + i] = w[3];
+    }
+}
+
+__global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __restrict__ basis,
+                                                                 const float* __restrict__ v_template,
+                                                                 const float* __restrict__ wT,
+                                                                 const float* __restrict__ A,
+                                                                 const float* __restrict__ coef, int B,
+                                                                 float* __restrict__ verts) {
+    __shared__ float sCoef[kPB][kNCoef + 3];
+    __shared__ float sA[kPB][288];
+    const int b0 = blockIdx.y * kPB;
+    const int nb = min(kPB, B - b0);
+    for (int i = threadIdx.x; i < kPB * kNCoef; i += kSkinThreads) {
+        int p = i / kNCoef, j = i % kNCoef;
+        sCoef[p][j] = (p < nb) ? coef[(size_t)(b0 + p) * kNCoef + j] : 0.f;
+    }
+    for (int i = threadIdx.x; i < kPB * 288; i += kSkinThreads) {
+        int p = i / 288, j = i % 288;
+        sA[p][j] = (p < nb) ? A[(size_t)(b0 + p) * 288 + j] : 0.f;
+    }
+    __syncthreads();
+    const int v = blockIdx.x * kSkinThreads + threadIdx.x;
+    if (v >= kV) return;
+    float px[kPB], py[kPB], pz[kPB];
+    {
+        const float t0 = v_template[3 * v], t1 = v_template[3 * v + 1], t2 = v_template[3 * v + 2];
+#pragma unroll
+        for (int p = 0; p < kPB; ++p) { px[p] = t0; py[p] = t1; pz[p] = t2; }
+    }
+    const float* bp = basis + 3 * v;
+#pragma unroll 4
+    for (int j = 0; j < kNCoef; ++j) {
+        const float d0 = bp[(size_t)j * kV3], d1 = bp[(size_t)j * kV3 + 1], d2 = bp[(size_t)j * kV3 + 2];
+#pragma unroll
+        for (int p = 0; p < kPB; ++p) {
+            const float c = sCoef[p][j];
+            px[p] = fmaf(c, d0, px[p]);
+            py[p] = fmaf(c, d1, py[p]);
+            pz[p] = fmaf(c, d2, pz[p]);
+        }
+    }
+    // T = sum_k w[v][k] A_k (3x4), vert = T [v_posed; 1]
+    float ox[kPB], oy[kPB], oz[kPB];
+#pragma unroll
+    for (int p = 0; p < kPB; ++p) ox[p] = oy[p] = oz[p] = 0.f;
+    for (int k = 0; k < kNJ; ++k) {
+        const float w = wT[(size_t)k * kV + v];
+#pragma unroll
+        for (int p = 0; p < kPB; ++p) {
+            const float* a = &sA[p][k * 12];
+            const float rx = fmaf(a[0], px[p], fmaf(a[1], py[p], fmaf(a[2], pz[p], a[3])));
+            const float ry = fmaf(a[4], px[p], fmaf(a[5], py[p], fmaf(a[6], pz[p], a[7])));
+            const float rz = fmaf(a[8], px[p], fmaf(a[9], py[p], fmaf(a[10], pz[p], a[11])));
+            ox[p] = fmaf(w, rx, ox[p]);
+            oy[p] = fmaf(w, ry, oy[p]);
+            oz[p] = fmaf(w, rz, oz[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < kPB; ++p) {
+        if (p < nb) {
+            float* o = verts + ((size_t)(b0 + p) * kV + v) * 3;
+            o[0] = ox[p]; o[1] = oy[p]; o[2] = oz[p];
+        }
+    }
+}
+
+// joints 24..44: picked vertices; joints 45..89: sparse regressor rows applied to the final vertices.
+__global__ __launch_bounds__(256) void smpl_extra_joints_kernel(const float* __restrict__ verts,
+                                                                const int* __restrict__ pick_ids,
+                                                                const int* __restrict__ csr_ptr,
+                                                                const int* __restrict__ csr_col,
+                                                                const float* __restrict__ csr_val,
+                                                                float* __restrict__ joints) {
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* vb = verts + (size_t)b * kV3;
+    float* jb = joints + (size_t)b * SPSP_NUM_OUT_JOINTS * 3;
+    if (threadIdx.x < 63) {
+        int j = threadIdx.x / 3, c = threadIdx.x % 3;
+        jb[(24 + j) * 3 + c] = vb[pick_ids[j] * 3 + c];
+    }
+    for (int r = wave; r < 45; r += 4) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int e = csr_ptr[r] + lane; e < csr_ptr[r + 1]; e += 64) {
+            const float w = csr_val[e];
+            const float* p = vb + csr_col[e] * 3;
+            sx = fmaf(w, p[0], sx);
+            sy = fmaf(w, p[1], sy);
+            sz = fmaf(w, p[2], sz);
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+        if (lane == 0) {
+            jb[(45 + r) * 3 + 0] = sx;
+            jb[(45 + r) * 3 + 1] = sy;
+            jb[(45 + r) * 3 + 2] = sz;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int spsp_smpl_load(spsp_ctx* ctx, const spsp_smpl_arrays* a, int max_batch, spsp_smpl** out) {
+    using namespace spsp;
+    SPSP_REQUIRE(ctx && a && out && max_batch > 0, "spsp_smpl_load: bad arguments");
+    SmplHostImage h;
+    const std::string err = smpl_prepare(*a, h);
+    SPSP_REQUIRE(err.empty(), "spsp_smpl_load: %s", err.c_str());
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));
+    spsp_smpl* s = new spsp_smpl;
+    s->max_batch = max_batch;
+    s->num_levels = h.num_levels;
+    std::memcpy(s->level_start, h.level_start, sizeof h.level_start);
+    std::memcpy(s->host_parents, h.parents, sizeof h.parents);
+    std::memcpy(s->face_ids, h.face_ids, sizeof h.face_ids);
+    int rc = SPSP_OK;
+#define TRY(x) do { rc = (x); if (rc != SPSP_OK) { delete s; return rc; } } while (0)
+    TRY(s->pool.upload(&s->basis, h.basis.data(), h.basis.size()));
+    TRY(s->pool.upload(&s->v_template, a->v_template, (size_t)kV3));
+    TRY(s->pool.upload(&s->wT, h.wT.data(), h.wT.size()));
+    TRY(s->pool.upload(&s->jconst, h.jconst.data(), h.jconst.size()));
+    TRY(s->pool.upload(&s->parents, h.parents, (size_t)kNJ));
+    TRY(s->pool.upload(&s->level_joints, h.level_joints.data(), h.level_joints.size()));
+    TRY(s->pool.upload(&s->d_level_start, h.level_start, (size_t)26));
+    TRY(s->pool.upload(&s->child_start, h.child_start, (size_t)25));
+    TRY(s->pool.upload(&s->child_list, h.child_list, (size_t)24));
+    TRY(s->pool.upload(&s->pick_ids, a->vertex_joint_ids, (size_t)21));
+    TRY(s->pool.upload(&s->csr_ptr, h.csr_ptr.data(), h.csr_ptr.size()));
+    TRY(s->pool.upload(&s->csr_col, h.csr_col.data(), h.csr_col.size()));
+    TRY(s->pool.upload(&s->csr_val, h.csr_val.data(), h.csr_val.size()));
+    TRY(s->pool.upload(&s->fitc, h.fitc.data(), h.fitc.size()));
+    TRY(s->pool.alloc(&s->ws_A, (size_t)max_batch * 288));
+    TRY(s->pool.alloc(&s->ws_coef, (size_t)max_batch * kNCoef));
+    TRY(s->pool.alloc(&s->ws_verts, (size_t)max_batch * kV3));
+#undef TRY
+    *out = s;
+    return SPSP_OK;
+}
+
+void spsp_smpl_free(spsp_smpl* s) { delete s; }
+
+int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B, float* verts,
+                      float* joints, void* stream) {
+    using namespace spsp;
+    SPSP_REQUIRE(ctx && s && R && betas, "spsp_smpl_forward: NULL argument");
+    SPSP_REQUIRE(B >= 0 && B <= s->max_batch, "spsp_smpl_forward: B=%d exceeds max_batch=%d", B, s->max_batch);
+    if (B == 0 || (!verts && !joints)) return SPSP_OK;
+    hipStream_t st = as_stream(stream);
+    smpl_chain_kernel<<<B, 64, 0, st>>>(R, betas, s->jconst, s->parents, s->level_joints, s->d_level_start,
+                                        s->num_levels, s->ws_A, s->ws_coef, joints);
+    SPSP_HIP_CHECK(hipGetLastError());
+    float* v = verts ? verts : s->ws_verts;
+    dim3 grid((kV + kSkinThreads - 1) / kSkinThreads, (B + kPB - 1) / kPB);
+    smpl_skin_kernel<<<grid, kSkinThreads, 0, st>>>(s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v);
+    SPSP_HIP_CHECK(hipGetLastError());
+    if (joints) {
+        smpl_extra_joints_kernel<<<B, 256, 0, st>>>(v, s->pick_ids, s->csr_ptr, s->csr_col, s->csr_val, joints);
+        SPSP_HIP_CHECK(hipGetLastError());
+    }
+    return SPSP_OK;
+}
+
+}  // extern "C"

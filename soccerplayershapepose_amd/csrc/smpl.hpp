@@ -1,0 +1,35 @@
+// Device-side SMPL model image shared by the forward kernels (smpl.hip) and the fit kernel (fit.hip).
+#pragma once
+#include "common.hpp"
+#include "smpl_consts.hpp"
+
+
+
+struct spsp_smpl {
+    spsp::DevicePool pool;
+    int max_batch;
+    // forward
+    float* basis;        // [217][20670]: rows 0..9 shapedirs^T, rows 10..216 posedirs
+    float* v_template;   // [20670]
+    float* wT;           // [24][6890] lbs weights, joint-major
+    float* jconst;       // [72 + 720] Jbar[24][3] then JS[10][72]
+    int* parents;        // [24]
+    int* level_joints;   // [24] joints sorted by depth (root first)
+    int level_start[26]; // host copy: level l occupies level_joints[level_start[l] .. level_start[l+1])
+    int num_levels;
+    int* d_level_start;  // device copy [26]
+    int* child_start;    // [25] children of joint k: child_list[child_start[k] .. child_start[k+1])
+    int* child_list;     // [24] (23 used)
+    int* pick_ids;       // [21]
+    int* csr_ptr;        // [46] extra-joint regressors (9 + 19 + 17 rows) in CSR
+    int* csr_col;
+    float* csr_val;
+    // fit
+    float* fitc;         // [kFcTotal]
+    int face_ids[spsp::kNFace];
+    // workspace
+    float* ws_A;         // [max_batch][24][12]
+    float* ws_coef;      // [max_batch][217]
+    float* ws_verts;     // [max_batch][6890][3] (only used when the caller passes verts == NULL)
+    int host_parents[24];
+};

@@ -1,0 +1,123 @@
+// Host-side preparation of the SMPL model image (HIP-free; shared by spsp_smpl_load and by the host
+// emulation under tests/emul): blend-basis re-layout, joint-major LBS weights, Jbar/JS, tree levels,
+// CSR of the extra joint regressors, and the packed fit constants.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smpl_consts.hpp"
+
+namespace spsp {
+
+struct SmplHostImage {
+    std::vector<float> basis, wT, jconst, fitc, csr_val;
+    std::vector<int> level_joints, csr_ptr, csr_col;
+    int parents[24];
+    int level_start[26];
+    int num_levels;
+    int child_start[25];
+    int child_list[24];
+    int face_ids[kNFace];
+};
+
+// Returns an empty string on success, else the reason.
+inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, bool want_forward = true) {
+    if (!(a.v_template && a.shapedirs && a.posedirs && a.J_regressor && a.lbs_weights && a.parents &&
+          a.vertex_joint_ids && a.J_regressor_extra && a.J_regressor_cocoplus && a.J_regressor_h36m))
+        return "NULL model array";
+    if (a.parents[0] >= 0) return "parents[0] must be -1 (root)";
+    for (int k = 1; k < kNJ; ++k)
+        if (a.parents[k] < 0 || a.parents[k] >= k) {
+            char buf[96];
+            snprintf(buf, sizeof buf, "parents[%d]=%d is not an earlier joint", k, a.parents[k]);
+            return buf;
+        }
+    for (int j = 0; j < 21; ++j)
+        if (a.vertex_joint_ids[j] < 0 || a.vertex_joint_ids[j] >= kV) return "vertex_joint_ids out of range";
+
+    if (want_forward) {
+        // blend basis [217][20670]: rows 0..9 shapedirs^T, rows 10..216 posedirs
+        h.basis.resize((size_t)kNCoef * kV3);
+        for (int v = 0; v < kV; ++v)
+            for (int c = 0; c < 3; ++c)
+                for (int i = 0; i < kNB; ++i)
+                    h.basis[(size_t)i * kV3 + 3 * v + c] = a.shapedirs[((size_t)v * 3 + c) * kNB + i];
+        std::memcpy(h.basis.data() + (size_t)kNB * kV3, a.posedirs, sizeof(float) * (size_t)kNP * kV3);
+        h.wT.resize((size_t)kNJ * kV);
+        for (int v = 0; v < kV; ++v)
+            for (int k = 0; k < kNJ; ++k) h.wT[(size_t)k * kV + v] = a.lbs_weights[(size_t)v * kNJ + k];
+        // CSR of the 45 extra regressor rows (9 extra + 19 cocoplus + 17 h36m)
+        const float* mats[3] = {a.J_regressor_extra, a.J_regressor_cocoplus, a.J_regressor_h36m};
+        const int rows[3] = {9, 19, 17};
+        h.csr_ptr.assign(1, 0);
+        for (int m = 0; m < 3; ++m)
+            for (int r = 0; r < rows[m]; ++r) {
+                for (int v = 0; v < kV; ++v) {
+                    const float w = mats[m][(size_t)r * kV + v];
+                    if (w != 0.f) { h.csr_col.push_back(v); h.csr_val.push_back(w); }
+                }
+                h.csr_ptr.push_back((int)h.csr_col.size());
+            }
+        if (h.csr_col.empty()) { h.csr_col.push_back(0); h.csr_val.push_back(0.f); }
+    }
+    // Jbar = J_regressor @ v_template [24][3], JS[i][k*3+c] = (J_regressor @ shapedirs)[k][c][i]; fp64 accumulation
+    h.jconst.assign(792, 0.f);
+    {
+        std::vector<double> acc(792, 0.0);
+        for (int k = 0; k < kNJ; ++k)
+            for (int v = 0; v < kV; ++v) {
+                const double w = a.J_regressor[(size_t)k * kV + v];
+                if (w == 0.0) continue;
+                for (int c = 0; c < 3; ++c) {
+                    acc[k * 3 + c] += w * a.v_template[3 * v + c];
+                    for (int i = 0; i < kNB; ++i)
+                        acc[72 + i * 72 + k * 3 + c] += w * a.shapedirs[((size_t)v * 3 + c) * kNB + i];
+                }
+            }
+        for (int i = 0; i < 792; ++i) h.jconst[i] = (float)acc[i];
+    }
+    // tree: levels by depth, children lists
+    {
+        int depth[kNJ], maxd = 0;
+        for (int k = 0; k < kNJ; ++k) {
+            h.parents[k] = a.parents[k];
+            depth[k] = k == 0 ? 0 : depth[a.parents[k]] + 1;
+            maxd = std::max(maxd, depth[k]);
+        }
+        h.num_levels = maxd + 1;
+        h.level_joints.clear();
+        for (int l = 0; l <= maxd; ++l) {
+            h.level_start[l] = (int)h.level_joints.size();
+            for (int k = 0; k < kNJ; ++k)
+                if (depth[k] == l) h.level_joints.push_back(k);
+        }
+        for (int l = maxd + 1; l < 26; ++l) h.level_start[l] = (int)h.level_joints.size();
+        int n = 0;
+        std::memset(h.child_list, 0, sizeof h.child_list);
+        for (int k = 0; k < kNJ; ++k) {
+            h.child_start[k] = n;
+            for (int c = 1; c < kNJ; ++c)
+                if (a.parents[c] == k) h.child_list[n++] = c;
+        }
+        h.child_start[24] = n;
+    }
+    // fit constants (face vertices = first 5 picked ids: nose, reye, leye, rear, lear)
+    h.fitc.assign(kFcTotal, 0.f);
+    std::memcpy(h.fitc.data() + kFcJbar, h.jconst.data(), sizeof(float) * 792);
+    for (int f = 0; f < kNFace; ++f) {
+        const int v = a.vertex_joint_ids[f];
+        h.face_ids[f] = v;
+        for (int c = 0; c < 3; ++c) {
+            h.fitc[kFcVt5 + f * 3 + c] = a.v_template[3 * v + c];
+            for (int i = 0; i < kNB; ++i) h.fitc[kFcS5 + i * 16 + f * 3 + c] = a.shapedirs[((size_t)v * 3 + c) * kNB + i];
+            for (int j = 0; j < kNP; ++j) h.fitc[kFcP5 + j * 16 + f * 3 + c] = a.posedirs[(size_t)j * kV3 + 3 * v + c];
+        }
+        for (int k = 0; k < kNJ; ++k) h.fitc[kFcW5 + f * 24 + k] = a.lbs_weights[(size_t)v * kNJ + k];
+    }
+    return "";
+}
+
+}  // namespace spsp

@@ -1,0 +1,76 @@
+// HOST EMULATION of the fit kernel -- test infrastructure only (never loaded by the product).
+// Runs the phases of soccerplayershapepose_amd/csrc/fit_core.hpp -- the very code the gfx950 kernel
+// executes -- with `for lane in 0..63` in place of the wavefront and a phase boundary in place of the
+// barrier, so the CPU test-suite can check the kernel's index math and its hand-derived gradient against
+// the autograd oracle without a GPU.  Built by tests/test_fit_emulation.py with g++.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../soccerplayershapepose_amd/csrc/fit_core.hpp"
+#include "../../soccerplayershapepose_amd/csrc/smpl_host.hpp"
+
+using namespace spsp;
+
+#define ALL_LANES(stmt) for (int lane = 0; lane < 64; ++lane) { stmt; }
+
+extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
+                           double beta1, double beta2, double eps, unsigned param_mask, float img_wh, float loss_wh,
+                           double loss_weight, int select_mode, float* R, float* betas, float* cam,
+                           const float* joints2d, int B, float* loss_hist, float* l2e_hist, float* grad_first) {
+    SmplHostImage h;
+    if (!smpl_prepare(*model, h, false).empty()) return -1;
+    const float* fitc = h.fitc.data();
+    const int *parents = h.parents, *level_joints = h.level_joints.data(), *level_start = h.level_start;
+    const int *child_start = h.child_start, *child_list = h.child_list;
+    const int num_levels = h.num_levels;
+    FitParams P;
+    P.iters = iters; P.lr = lr; P.beta1 = beta1; P.beta2 = beta2; P.eps = eps;
+    P.param_mask = param_mask; P.img_wh = img_wh; P.loss_wh = loss_wh;
+    P.log_var = (float)(-std::log(loss_weight + 1e-6));
+    P.weight = std::exp(-P.log_var);
+    P.select_mode = select_mode; P.num_levels = num_levels;
+    std::vector<FitShared> sv(1);
+    FitShared& s = sv[0];
+    for (int b = 0; b < B; ++b) {
+        FitLane r[64];
+        float* Rb = R + (size_t)b * 216; float* bb = betas + (size_t)b * 10; float* cb = cam + (size_t)b * 3;
+        ALL_LANES(fit_init(s, r[lane], lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb,
+                           cb, joints2d + (size_t)b * 34));
+        float* lh = loss_hist ? loss_hist + (size_t)b * iters : nullptr;
+        float* eh = l2e_hist ? l2e_hist + (size_t)b * iters : nullptr;
+        double b1t = 1.0, b2t = 1.0;
+        const int L = num_levels;
+        for (int it = 0; it < iters; ++it) {
+            b1t *= beta1; b2t *= beta2;
+            const float step_size = (float)(lr / (1.0 - b1t));
+            const float bc2_sqrt = (float)std::sqrt(1.0 - b2t);
+            ALL_LANES(fit_p1(s, lane));
+            ALL_LANES(fit_p2(s, lane));
+            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, lane, l)); }
+            ALL_LANES(fit_p4(s, lane));
+            ALL_LANES(fit_p5(s, lane));
+            ALL_LANES(fit_p6(s, lane, P));
+            ALL_LANES(fit_p7(s, lane));
+            ALL_LANES(fit_p8(s, lane, P, it, lh, eh));
+            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, lane, l)); }
+            ALL_LANES(fit_p10(s, lane));
+            ALL_LANES(fit_p11(s, lane));
+            if (it == 0 && grad_first) {      // gradient of the first iteration, record order [cam|R|betas]
+                float* g = grad_first + (size_t)b * kNumPrm;
+                for (int p = 0; p < kNumPrm; ++p)
+                    g[p] = p < kPrmR ? s.red[2 + p]
+                         : p < kPrmBeta ? s.grad[p]
+                         : (s.part[p - kPrmBeta] + s.part[16 + p - kPrmBeta]) + (s.part[32 + p - kPrmBeta] + s.part[48 + p - kPrmBeta]);
+            }
+            ALL_LANES(fit_p12(s, r[lane], lane, P, step_size, bc2_sqrt));
+        }
+        const float* src = (select_mode == SPSP_FIT_SELECT_BEST_L2E) ? s.best : s.prm;
+        for (int p = 0; p < kNumPrm; ++p) {
+            if (p < kPrmR) cb[p] = src[p];
+            else if (p < kPrmBeta) Rb[p - kPrmR] = src[p];
+            else bb[p - kPrmBeta] = src[p];
+        }
+    }
+    return 0;
+}
