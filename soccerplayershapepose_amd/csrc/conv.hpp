@@ -1,0 +1,35 @@
+// Implicit-GEMM convolution on gfx950 MFMA -- interface between regressor.hip (layer plan) and conv.hip.
+#pragma once
+#include "common.hpp"
+
+namespace spsp {
+
+// All activations are bf16 NHWC with a ZERO BORDER baked into the buffer (3 px for the network input,
+// 1 px for every feature map).  The border makes every filter tap of every output pixel an in-bounds
+// read, so the gather has no masks: the address of tap-step `s` of output pixel m is
+//     in + in_off + row_base(m) + step_off(s),      row_base(m) = b*in_img + ho*stride*in_row + wo*stride*in_pix
+// and one K-step is a CONTIGUOUS run of BK bf16 values of the input:
+//   3x3 / 1x1 convs (Cin >= 64): step = (tap r, tap c, 64-channel chunk ch)  -> step_off = r*in_row + c*in_pix + ch*64
+//   conv1 7x7/2 (Cin = 18):      step = kernel row r; the 7 taps x 18 channels of that row are 126 contiguous
+//                                values, padded to BK = 128 with two zero weights -> step_off = r*in_row
+struct ConvArgs {
+    const uint16_t* in;
+    const uint16_t* w;       // [N][nsteps*BK] bf16, K ordered like the steps
+    const float* bias;       // [N] folded BN bias
+    const uint16_t* res;     // residual, addressed like `out` (may be null)
+    uint16_t* out;
+    float* pool_out;         // if non-null: [B][N] fp32 mean over the image's Ho*Wo pixels (fused global avg-pool;
+                             // requires BM == Ho*Wo so one M-tile is one image); `out` is then not written
+    int in_img, in_row, in_pix, in_off;
+    int out_img, out_row, out_pix, out_off;
+    int Ho, Wo, M, N;
+    int stride;
+    int kw_steps, chunks, nsteps;
+    int relu;
+};
+
+enum ConvTile { kTile128x64 = 0, kTile128x128, kTile64x128, kTile64x64, kTileConv1 };
+
+int launch_conv(const ConvArgs& a, ConvTile tile, hipStream_t stream);
+
+}  // namespace spsp

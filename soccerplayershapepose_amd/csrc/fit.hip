@@ -4,8 +4,8 @@
 // players are independent, so a batch fills one CU per player.
 #include <cmath>
 
-#include "fit_core.hpp"
 #include "smpl.hpp"
+#include "fit_core.hpp"
 
 namespace {
 using namespace spsp;

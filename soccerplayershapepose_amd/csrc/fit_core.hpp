@@ -25,7 +25,7 @@
 #include "smpl_consts.hpp"
 
 #if defined(__HIPCC__)
-#define SPSP_HD __host__ __device__ __forceinline__
+#define SPSP_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define SPSP_HD inline
 #endif

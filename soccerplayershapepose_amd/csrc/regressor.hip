@@ -1,0 +1,379 @@
+// SingleInputRegressor(18, 18, 3) for gfx950: ResNet-18 encoder (PR/models/resnet.py:124-216) as a plan of
+// MFMA implicit-GEMM convolutions (conv.hip) over zero-bordered NHWC bf16 feature maps, + the IEF MLP
+// (PR/models/ief_module.py:48-64) in fp32.  Eval-mode BatchNorm is folded into weights/bias at load.
+#include <cmath>
+#include <string>
+
+#include "conv.hpp"
+
+namespace {
+using namespace spsp;
+
+constexpr int kWH = SPSP_PROXY_WH, kCin = SPSP_PROXY_C, kPad = SPSP_PROXY_PAD;
+constexpr int kWHp = kWH + 2 * kPad;                       // 262
+constexpr size_t kNativeElems = (size_t)kWHp * kWHp * kCin;
+constexpr int kFeat = 512, kNPar = 157, kHid = 512;
+
+struct ConvDesc { const char* name; const char* bn; int cout, cin, k, stride; };
+const ConvDesc kConvs[SPSP_NUM_CONVS] = {
+    {"image_encoder.conv1", "image_encoder.bn1", 64, 18, 7, 2},
+    {"image_encoder.layer1.0.conv1", "image_encoder.layer1.0.bn1", 64, 64, 3, 1},
+    {"image_encoder.layer1.0.conv2", "image_encoder.layer1.0.bn2", 64, 64, 3, 1},
+    {"image_encoder.layer1.1.conv1", "image_encoder.layer1.1.bn1", 64, 64, 3, 1},
+    {"image_encoder.layer1.1.conv2", "image_encoder.layer1.1.bn2", 64, 64, 3, 1},
+    {"image_encoder.layer2.0.conv1", "image_encoder.layer2.0.bn1", 128, 64, 3, 2},
+    {"image_encoder.layer2.0.conv2", "image_encoder.layer2.0.bn2", 128, 128, 3, 1},
+    {"image_encoder.layer2.0.downsample.0", "image_encoder.layer2.0.downsample.1", 128, 64, 1, 2},
+    {"image_encoder.layer2.1.conv1", "image_encoder.layer2.1.bn1", 128, 128, 3, 1},
+    {"image_encoder.layer2.1.conv2", "image_encoder.layer2.1.bn2", 128, 128, 3, 1},
+    {"image_encoder.layer3.0.conv1", "image_encoder.layer3.0.bn1", 256, 128, 3, 2},
+    {"image_encoder.layer3.0.conv2", "image_encoder.layer3.0.bn2", 256, 256, 3, 1},
+    {"image_encoder.layer3.0.downsample.0", "image_encoder.layer3.0.downsample.1", 256, 128, 1, 2},
+    {"image_encoder.layer3.1.conv1", "image_encoder.layer3.1.bn1", 256, 256, 3, 1},
+    {"image_encoder.layer3.1.conv2", "image_encoder.layer3.1.bn2", 256, 256, 3, 1},
+    {"image_encoder.layer4.0.conv1", "image_encoder.layer4.0.bn1", 512, 256, 3, 2},
+    {"image_encoder.layer4.0.conv2", "image_encoder.layer4.0.bn2", 512, 512, 3, 1},
+    {"image_encoder.layer4.0.downsample.0", "image_encoder.layer4.0.downsample.1", 512, 256, 1, 2},
+    {"image_encoder.layer4.1.conv1", "image_encoder.layer4.1.bn1", 512, 512, 3, 1},
+    {"image_encoder.layer4.1.conv2", "image_encoder.layer4.1.bn2", 512, 512, 3, 1},
+};
+
+// ---- layout kernels -------------------------------------------------------------------------------------
+// NCHW fp32 [B,18,256,256] -> native [B,262,262,18] bf16 (interior + zero border).
+__global__ void proxy_pack_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst) {
+    const int xp = blockIdx.x * blockDim.x + threadIdx.x, yp = blockIdx.y, b = blockIdx.z;
+    if (xp >= kWHp) return;
+    const int x = xp - kPad, y = yp - kPad;
+    const bool inside = x >= 0 && x < kWH && y >= 0 && y < kWH;
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst + ((size_t)b * kWHp * kWHp + (size_t)yp * kWHp + xp) * kCin);
+    const float* s = src + (size_t)b * kCin * kWH * kWH + (size_t)y * kWH + x;
+#pragma unroll
+    for (int c = 0; c < kCin; c += 2) {
+        float v0 = 0.f, v1 = 0.f;
+        if (inside) { v0 = s[(size_t)c * kWH * kWH]; v1 = s[(size_t)(c + 1) * kWH * kWH]; }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        f32x2 v = {v0, v1};
+        d[c / 2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    }
+}
+
+// 3x3/2 max-pool, pad 1 (resnet.py:149) on a post-ReLU map: the zero border equals -inf padding.
+// in [B][2*Ho+2][2*Wo+2][C] -> out [B][Ho+2][Wo+2][C] interior; one thread per (pixel, 8 channels).
+__global__ void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Ho, int Wo, int C) {
+    const int groups = C / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * Ho * Wo * groups;
+    if (idx >= total) return;
+    const int g = idx % groups;
+    size_t t = idx / groups;
+    const int wo = t % Wo; t /= Wo;
+    const int ho = t % Ho;
+    const int b = (int)(t / Ho);
+    const int Wi = 2 * Wo + 2, Hi = 2 * Ho + 2;
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 0.f;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const uint4 v = *reinterpret_cast<const uint4*>(in + (((size_t)b * Hi + 2 * ho + r) * Wi + 2 * wo + c) * C + g * 8);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m[2 * i] = fmaxf(m[2 * i], __builtin_bit_cast(float, u[i] << 16));
+                m[2 * i + 1] = fmaxf(m[2 * i + 1], __builtin_bit_cast(float, u[i] & 0xFFFF0000u));
+            }
+        }
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)   // values are exact bf16 already: truncation == rounding
+        o[i] = (__builtin_bit_cast(uint32_t, m[2 * i]) >> 16) | (__builtin_bit_cast(uint32_t, m[2 * i + 1]) & 0xFFFF0000u);
+    *reinterpret_cast<uint4*>(out + (((size_t)b * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * C + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// padded NHWC bf16 -> NCHW fp32 (parity tap)
+__global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int pad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * C * H * W;
+    if (idx >= total) return;
+    const int x = idx % W;
+    size_t t = idx / W;
+    const int y = t % H; t /= H;
+    const int c = t % C;
+    const int b = (int)(t / C);
+    const uint16_t v = in[(((size_t)b * (H + 2 * pad) + y + pad) * (W + 2 * pad) + x + pad) * C + c];
+    out[idx] = __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+
+// ---- IEF fully-connected layer (fp32): out[b][n] = act(bias[n] + sum_k x[b][k] W[n][k]) (+ out, if accumulate)
+// The input row is the concatenation [x0[b][0:K0] | x1[b][0:K1]] (torch.cat([feat, params]), ief_module.py:55,59).
+// One wave per output neuron and group of 8 players; lanes stride over k (coalesced weight-row reads).
+constexpr int kFcPB = 8;
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x0, int K0, const float* __restrict__ x1, int K1,
+                                                 const float* __restrict__ W, const float* __restrict__ bias, int N, int B,
+                                                 int relu, int accumulate, float* __restrict__ out, int out_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    const int b0 = blockIdx.y * kFcPB;
+    if (n >= N) return;
+    const int K = K0 + K1;
+    const float* wr = W + (size_t)n * K;
+    float acc[kFcPB];
+#pragma unroll
+    for (int p = 0; p < kFcPB; ++p) acc[p] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = wr[k];
+#pragma unroll
+        for (int p = 0; p < kFcPB; ++p) {
+            const int b = min(b0 + p, B - 1);
+            const float xv = k < K0 ? x0[(size_t)b * K0 + k] : x1[(size_t)b * K1 + (k - K0)];
+            acc[p] = fmaf(w, xv, acc[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < kFcPB; ++p) {
+        float v = acc[p];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[p] = v;
+    }
+    if (lane < kFcPB && b0 + lane < B) {
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < kFcPB; ++p) v = (lane == p) ? acc[p] : v;
+        v += bias[n];
+        if (relu) v = fmaxf(v, 0.f);
+        float* o = out + (size_t)(b0 + lane) * out_stride + n;
+        *o = accumulate ? (*o + v) : v;
+    }
+}
+
+__global__ void init_params_kernel(const float* __restrict__ init, int B, float* __restrict__ params) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * kNPar) params[i] = init[i % kNPar];
+}
+
+__global__ void split_params_kernel(const float* __restrict__ params, int B, float* __restrict__ cam,
+                                    float* __restrict__ pose, float* __restrict__ betas) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * kNPar) return;
+    const int b = i / kNPar, j = i % kNPar;
+    const float v = params[i];
+    if (j < 3) cam[b * 3 + j] = v;
+    else if (j < 147) pose[b * 144 + (j - 3)] = v;
+    else betas[b * 10 + (j - 147)] = v;
+}
+
+}  // namespace
+
+struct spsp_regressor {
+    spsp::DevicePool pool;
+    int max_batch;
+    int ief_iters;
+    uint16_t* w[SPSP_NUM_CONVS];
+    float* bias[SPSP_NUM_CONVS];
+    float* fcw[3];
+    float* fcb[3];
+    float* init_params;
+    // feature maps (bf16, zero border)
+    uint16_t* x0;          // [B][262][262][18]
+    uint16_t* c1;          // [B][130][130][64]
+    uint16_t* p1;          // [B][66][66][64] max-pool output
+    uint16_t* l[4][3];     // layer L: [B][S+2][S+2][C], S = 64,32,16,8; C = 64,128,256,512
+    float *feats, *params, *h1, *h2;
+    const uint16_t* stage_ptr[6];
+    int last_B;
+};
+
+namespace {
+
+const int kLayerS[4] = {64, 32, 16, 8};
+const int kLayerC[4] = {64, 128, 256, 512};
+
+// conv `ci` reading map `in` (spatial Si, channels Ci, border bi) writing map `out` (spatial So, border 1)
+int run_conv(spsp_regressor* r, int ci, const uint16_t* in, int Si, int bi, uint16_t* out, const uint16_t* res, int relu,
+             int B, ConvTile tile, float* pool_out, hipStream_t st) {
+    const ConvDesc& d = kConvs[ci];
+    ConvArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = in; a.w = r->w[ci]; a.bias = r->bias[ci]; a.res = res; a.out = out; a.pool_out = pool_out;
+    const int Wi = Si + 2 * bi;
+    a.in_pix = d.cin; a.in_row = Wi * d.cin; a.in_img = Wi * Wi * d.cin;
+    const int conv_pad = d.k / 2;
+    a.in_off = (bi - conv_pad) * (a.in_row + a.in_pix);
+    const int So = Si / d.stride;
+    a.out_pix = d.cout; a.out_row = (So + 2) * d.cout; a.out_img = (So + 2) * (So + 2) * d.cout;
+    a.out_off = a.out_row + a.out_pix;
+    a.Ho = So; a.Wo = So; a.M = B * So * So; a.N = d.cout;
+    a.stride = d.stride;
+    if (ci == 0) { a.kw_steps = 1; a.chunks = 1; a.nsteps = 7; }
+    else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
+    a.relu = relu;
+    return launch_conv(a, tile, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* spsp_conv_name(int i) { return (i >= 0 && i < SPSP_NUM_CONVS) ? kConvs[i].name : nullptr; }
+const char* spsp_conv_bn_name(int i) { return (i >= 0 && i < SPSP_NUM_CONVS) ? kConvs[i].bn : nullptr; }
+size_t spsp_proxy_native_bytes(void) { return kNativeElems * 2; }
+
+int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_batch, int precision,
+                        spsp_regressor** out) {
+    SPSP_REQUIRE(ctx && w && out && max_batch > 0, "spsp_regressor_load: bad arguments");
+    SPSP_REQUIRE(precision == 0, "spsp_regressor_load: precision %d not available in this build (0 = bf16 MFMA)", precision);
+    SPSP_REQUIRE(w->ief_iters >= 0 && w->ief_iters <= 16, "spsp_regressor_load: ief_iters=%d", w->ief_iters);
+    for (int i = 0; i < SPSP_NUM_CONVS; ++i)
+        SPSP_REQUIRE(w->conv[i].weight && w->conv[i].bn_weight && w->conv[i].bn_bias && w->conv[i].bn_mean && w->conv[i].bn_var,
+                     "spsp_regressor_load: NULL array for %s", kConvs[i].name);
+    for (int i = 0; i < 3; ++i) SPSP_REQUIRE(w->fc_weight[i] && w->fc_bias[i], "spsp_regressor_load: NULL fc%d", i + 1);
+    SPSP_REQUIRE(w->init_params, "spsp_regressor_load: NULL init_params");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));
+    spsp_regressor* r = new spsp_regressor;
+    r->max_batch = max_batch;
+    r->ief_iters = w->ief_iters;
+    r->last_B = 0;
+    int rc = SPSP_OK;
+#define TRY(x) do { rc = (x); if (rc != SPSP_OK) { delete r; return rc; } } while (0)
+    for (int ci = 0; ci < SPSP_NUM_CONVS; ++ci) {
+        const ConvDesc& d = kConvs[ci];
+        const spsp_conv_bn& c = w->conv[ci];
+        const int ktot = ci == 0 ? 7 * 128 : d.k * d.k * d.cin;
+        std::vector<uint16_t> wt((size_t)d.cout * ktot, 0);
+        std::vector<float> bias(d.cout);
+        for (int n = 0; n < d.cout; ++n) {
+            SPSP_REQUIRE(c.bn_var[n] + 1e-5 > 0.0, "spsp_regressor_load: %s running_var[%d] <= -eps", d.bn, n);
+            const double s = (double)c.bn_weight[n] / std::sqrt((double)c.bn_var[n] + 1e-5);
+            bias[n] = (float)((double)c.bn_bias[n] - (double)c.bn_mean[n] * s);
+            for (int cin = 0; cin < d.cin; ++cin)
+                for (int kr = 0; kr < d.k; ++kr)
+                    for (int kc = 0; kc < d.k; ++kc) {
+                        const float wv = (float)((double)c.weight[(((size_t)n * d.cin + cin) * d.k + kr) * d.k + kc] * s);
+                        const size_t kidx = ci == 0 ? (size_t)kr * 128 + kc * d.cin + cin
+                                                    : ((size_t)kr * d.k + kc) * d.cin + cin;
+                        wt[(size_t)n * ktot + kidx] = f32_to_bf16_host(wv);
+                    }
+        }
+        TRY(r->pool.upload(&r->w[ci], wt.data(), wt.size()));
+        TRY(r->pool.upload(&r->bias[ci], bias.data(), bias.size()));
+    }
+    const int fcn[3] = {kHid, kHid, kNPar}, fck[3] = {kFeat + kNPar, kHid, kHid};
+    for (int i = 0; i < 3; ++i) {
+        TRY(r->pool.upload(&r->fcw[i], w->fc_weight[i], (size_t)fcn[i] * fck[i]));
+        TRY(r->pool.upload(&r->fcb[i], w->fc_bias[i], (size_t)fcn[i]));
+    }
+    TRY(r->pool.upload(&r->init_params, w->init_params, (size_t)kNPar));
+    const size_t B = max_batch;
+    TRY(r->pool.alloc(&r->x0, B * kNativeElems, true));
+    TRY(r->pool.alloc(&r->c1, B * 130 * 130 * 64, true));
+    TRY(r->pool.alloc(&r->p1, B * 66 * 66 * 64, true));
+    for (int L = 0; L < 4; ++L)
+        for (int j = 0; j < 3; ++j)
+            TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
+    TRY(r->pool.alloc(&r->feats, B * kFeat));
+    TRY(r->pool.alloc(&r->params, B * kNPar));
+    TRY(r->pool.alloc(&r->h1, B * kHid));
+    TRY(r->pool.alloc(&r->h2, B * kHid));
+#undef TRY
+    *out = r;
+    return SPSP_OK;
+}
+
+void spsp_regressor_free(spsp_regressor* r) { delete r; }
+
+int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_out, void* stream) {
+    SPSP_REQUIRE(ctx && proxy_nchw && native_out && B >= 0, "spsp_proxy_pack: bad arguments");
+    if (B == 0) return SPSP_OK;
+    dim3 grid((kWHp + 63) / 64, kWHp, B);
+    proxy_pack_kernel<<<grid, 64, 0, as_stream(stream)>>>(proxy_nchw, static_cast<uint16_t*>(native_out));
+    SPSP_HIP_CHECK(hipGetLastError());
+    return SPSP_OK;
+}
+
+int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, float* cam,
+                           float* pose6d, float* betas, float* feats, void* stream) {
+    SPSP_REQUIRE(ctx && r && proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
+    SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_forward: B=%d exceeds max_batch=%d", B, r->max_batch);
+    SPSP_REQUIRE(proxy_format == SPSP_PROXY_NCHW_F32 || proxy_format == SPSP_PROXY_NATIVE,
+                 "spsp_regressor_forward: unknown proxy_format %d", proxy_format);
+    if (B == 0) return SPSP_OK;
+    hipStream_t st = as_stream(stream);
+    int rc;
+#define TRY(x) do { rc = (x); if (rc != SPSP_OK) return rc; } while (0)
+    const uint16_t* x0 = static_cast<const uint16_t*>(proxy);
+    if (proxy_format == SPSP_PROXY_NCHW_F32) {
+        TRY(spsp_proxy_pack(ctx, static_cast<const float*>(proxy), B, r->x0, stream));
+        x0 = r->x0;
+    }
+    // stem
+    TRY(run_conv(r, 0, x0, kWH, kPad, r->c1, nullptr, 1, B, kTileConv1, nullptr, st));
+    {
+        const size_t total = (size_t)B * 64 * 64 * 8;
+        maxpool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(r->c1, r->p1, B, 64, 64, 64);
+        SPSP_HIP_CHECK(hipGetLastError());
+    }
+    r->stage_ptr[0] = r->c1;
+    r->stage_ptr[1] = r->p1;
+    // residual stages
+    const uint16_t* x = r->p1;
+    int xs = 64;           // spatial size of x
+    int ci = 1;
+    for (int L = 0; L < 4; ++L) {
+        const int S = kLayerS[L];
+        ConvTile tile = L == 0 ? kTile128x64 : L == 1 ? (B * 8 >= 256 ? kTile128x128 : kTile64x128) : L == 2 ? kTile64x128 : kTile64x64;
+        uint16_t *ba = r->l[L][0], *bb = r->l[L][1], *bc = r->l[L][2];
+        if (L == 0) {
+            TRY(run_conv(r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   = relu(bn1(conv1(x)))
+            TRY(run_conv(r, ci + 1, ba, S, 1, bb, x, 1, B, tile, nullptr, st));              // out = relu(bn2(conv2(t)) + x)
+            ci += 2;
+            TRY(run_conv(r, ci, bb, S, 1, ba, nullptr, 1, B, tile, nullptr, st));
+            TRY(run_conv(r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));
+            ci += 2;
+            x = bc;
+        } else {
+            TRY(run_conv(r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   (stride 2)
+            TRY(run_conv(r, ci + 2, x, xs, 1, bb, nullptr, 0, B, tile, nullptr, st));        // identity = downsample(x)
+            TRY(run_conv(r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));             // out -> bc
+            ci += 3;
+            TRY(run_conv(r, ci, bc, S, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t
+            float* pool = (L == 3) ? r->feats : nullptr;
+            TRY(run_conv(r, ci + 1, ba, S, 1, bb, bc, 1, B, tile, pool, st));                // out -> bb (+ avg-pool)
+            ci += 2;
+            x = bb;
+        }
+        xs = S;
+        r->stage_ptr[2 + L] = x;
+    }
+    r->last_B = B;
+    // IEF (ief_module.py:48-64): params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) }
+    init_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, r->params);
+    SPSP_HIP_CHECK(hipGetLastError());
+    const dim3 gh((kHid + 3) / 4, (B + kFcPB - 1) / kFcPB), go((kNPar + 3) / 4, (B + kFcPB - 1) / kFcPB);
+    for (int it = 0; it < r->ief_iters; ++it) {
+        fc_kernel<<<gh, 256, 0, st>>>(r->feats, kFeat, r->params, kNPar, r->fcw[0], r->fcb[0], kHid, B, 1, 0, r->h1, kHid);
+        fc_kernel<<<gh, 256, 0, st>>>(r->h1, kHid, nullptr, 0, r->fcw[1], r->fcb[1], kHid, B, 1, 0, r->h2, kHid);
+        fc_kernel<<<go, 256, 0, st>>>(r->h2, kHid, nullptr, 0, r->fcw[2], r->fcb[2], kNPar, B, 0, 1, r->params, kNPar);
+        SPSP_HIP_CHECK(hipGetLastError());
+    }
+    split_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->params, B, cam, pose6d, betas);
+    SPSP_HIP_CHECK(hipGetLastError());
+    if (feats) SPSP_HIP_CHECK(hipMemcpyAsync(feats, r->feats, (size_t)B * kFeat * sizeof(float), hipMemcpyDeviceToDevice, st));
+#undef TRY
+    return SPSP_OK;
+}
+
+int spsp_regressor_read_stage(spsp_ctx* ctx, spsp_regressor* r, int stage, int B, float* out_nchw, void* stream) {
+    SPSP_REQUIRE(ctx && r && out_nchw, "spsp_regressor_read_stage: NULL argument");
+    SPSP_REQUIRE(stage >= 0 && stage < 6, "spsp_regressor_read_stage: stage %d out of range", stage);
+    SPSP_REQUIRE(B > 0 && B <= r->last_B, "spsp_regressor_read_stage: B=%d but the last forward ran %d crops", B, r->last_B);
+    const int S = stage == 0 ? 128 : kLayerS[stage < 2 ? 0 : stage - 2];
+    const int C = stage < 2 ? 64 : kLayerC[stage - 2];
+    const size_t total = (size_t)B * C * S * S;
+    read_stage_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(r->stage_ptr[stage], out_nchw, B, S, S, C, 1);
+    SPSP_HIP_CHECK(hipGetLastError());
+    return SPSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""The per-player fit loops and the batched inference pipeline, re-designed for gfx950.
+
+Mirrors (same names, argument meaning, in-place contract):
+  optimize_camera           PR/PyTorch3DTest.py:3055-3124   cam + global-orientation fit, 50 Adam steps, lr 0.01
+  single_view_optimization  PR/player_recon.py:1172-1294    pose + shape + camera fit ("theta fit"), lr 1e-3
+  evaluate_model_2d core    PR/PyTorch3DTest.py:3738-3776   regressor -> rot6d -> per-player fit -> SMPL -> 2-D verts
+The reference runs these one player at a time with a full SMPL.forward + autograd per iteration; here a
+whole batch of players is ONE kernel launch (csrc/fit.hip), one wavefront per player."""
+import ctypes as C
+from types import SimpleNamespace
+
+import torch
+
+from . import _abi, config
+from . import runtime as rt
+from .utils.cam_utils import (convert_weak_perspective_to_camera_translation_torch,
+                              orthographic_project_to_pixels)
+from .utils.rigid_transform_utils import rot6d_to_rotmat
+
+
+def _fit_config(r, variant, iters, lr, param_mask, select_mode):
+    cfg = _abi.FitConfig()
+    r.lib.spsp_fit_config_default(C.byref(cfg), variant)
+    if iters is not None:
+        cfg.iters = int(iters)
+    if lr is not None:
+        cfg.lr = float(lr)
+    if param_mask is not None:
+        cfg.param_mask = int(param_mask)
+    if select_mode is not None:
+        cfg.select_mode = int(select_mode)
+    return cfg
+
+
+def fit_players(smpl, full_pose, betas, cam_wp, joints2D, *, variant, iters=None, lr=None, param_mask=None,
+                select_mode=None, return_history=False):
+    """Batched fit, IN PLACE on contiguous CUDA fp32 tensors full_pose [B,24,3,3], betas [B,10], cam_wp [B,3].
+    joints2D [B,17,>=2] detected joints in 512-px space."""
+    for name, t, shp in (('full_pose', full_pose, (24, 3, 3)), ('betas', betas, (10,)), ('cam_wp', cam_wp, (3,))):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                and tuple(t.shape[1:]) == shp):
+            raise ValueError(f'fit_players: {name} must be a contiguous CUDA fp32 tensor [B,{",".join(map(str, shp))}]')
+    B = full_pose.shape[0]
+    r = rt.get(full_pose.device)
+    j2d = rt.dev_f32(torch.as_tensor(joints2D)[..., :2], r.device).reshape(B, 17, 2).contiguous()
+    cfg = _fit_config(r, variant, iters, lr, param_mask, select_mode)
+    loss = l2e = None
+    if return_history:
+        loss = torch.empty((B, cfg.iters), dtype=torch.float32, device=r.device)
+        l2e = torch.empty((B, cfg.iters), dtype=torch.float32, device=r.device)
+    smpl.to(r.device)
+    r.check(r.lib.spsp_fit(r.ctx, smpl.handle, C.byref(cfg), rt.ptr(full_pose), rt.ptr(betas), rt.ptr(cam_wp),
+                           rt.ptr(j2d), B, rt.ptr(loss), rt.ptr(l2e), r.stream()), 'spsp_fit')
+    return (loss, l2e) if return_history else None
+
+
+def optimize_camera(body_pose, global_orient, betas, joints2D, silhouette, cam_wp, smpl=None, lr=None, iters=None):
+    """`optimize_camera(body_pose, global_orient, betas, joints2D, silhouette, cam_wp) -> None`
+    (`PR/PyTorch3DTest.py:3055`): fits cam_wp [1,3] and global_orient [1,1,3,3] IN PLACE (the arguments may be
+    views into batch tensors, as at :3766-3767); `silhouette` is accepted and ignored, as its render never enters
+    the reference loss.  `smpl` replaces the per-call `SMPL(config.SMPL_MODEL_DIR)` construction (:3057)."""
+    if smpl is None:
+        raise ValueError('optimize_camera: pass smpl= (the reference re-reads the SMPL pickle per player, :3057)')
+    dev = global_orient.device
+    B = global_orient.shape[0]
+    full = torch.cat([global_orient.reshape(B, 1, 3, 3), body_pose.reshape(B, 23, 3, 3)], dim=1).float().contiguous()
+    b = betas.detach().float().contiguous().clone()
+    cam = cam_wp.detach().float().contiguous().clone()
+    j = torch.as_tensor(joints2D)
+    fit_players(smpl, full, b, cam, j.reshape(B, 17, -1), variant=0, iters=iters, lr=lr)
+    with torch.no_grad():
+        global_orient.copy_(full[:, :1].reshape(global_orient.shape).to(dev))
+        cam_wp.copy_(cam.to(dev))
+    return None
+
+
+def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp, joints2D, interation=None, lr=None,
+                             select_mode=_abi.FIT_SELECT_LAST):
+    """Fit body of `single_view_optimization` (`PR/player_recon.py:1172-1294`) for a batch of players.
+    Returns the record the reference saves (:1293-1294) -- body_pose [B,23,3,3], global_orient [B,1,3,3],
+    betas [B,10], translation [B,3] -- plus cam_wp.  Inputs are not modified.  select_mode BEST_L2E picks the
+    lowest-joints2D_l2es iterate (the reference's rule also gates on a rasterised silhouette, out of scope;
+    SURVEY a11) and, unlike the reference (:1264), returns the OPTIMISED body pose."""
+    B = betas.shape[0]
+    full = torch.cat([rt.dev_f32(global_orient).reshape(B, 1, 3, 3), rt.dev_f32(body_pose).reshape(B, 23, 3, 3)], dim=1).contiguous()
+    b = rt.dev_f32(betas).clone()
+    cam = rt.dev_f32(pred_cam_wp).clone()
+    iters = interation if interation is not None else config.texture_single_opt_interation
+    fit_players(smpl, full, b, cam, joints2D, variant=1, iters=iters, lr=lr, select_mode=select_mode)
+    translation = convert_weak_perspective_to_camera_translation_torch(cam, config.FOCAL_LENGTH, config.proxy_rep_input_wh)
+    return SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam)
+
+
+def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape', iters=50, lr=None,
+                        select_mode=_abi.FIT_SELECT_LAST, return_vertices2d=False):
+    """The hot path end to end for one batch (`evaluate_model_2d` core, `PR/PyTorch3DTest.py:3738-3776`):
+        proxy_rep [B,18,256,256] -> regressor -> rot6d -> fit ('camera' = optimize_camera per player,
+        'pose_shape' = single_view_optimization per player, None = skip) -> SMPL forward.
+    Returns cam [B,3], rotmats [B,24,3,3], betas [B,10], vertices [B,6890,3], joints [B,90,3], translation."""
+    cam, pose6d, betas = regressor(proxy_rep)
+    B = cam.shape[0]
+    R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
+    if fit is not None:
+        variant = {'camera': 0, 'pose_shape': 1}[fit]
+        fit_players(smpl, R, betas, cam, joints2D, variant=variant, iters=iters, lr=lr, select_mode=select_mode)
+    out = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+    res = SimpleNamespace(cam=cam, rotmats=R, betas=betas, vertices=out.vertices, joints=out.joints,
+                          translation=convert_weak_perspective_to_camera_translation_torch(
+                              cam, config.FOCAL_LENGTH, config.proxy_rep_input_wh))
+    if return_vertices2d:   # PR/PyTorch3DTest.py:3774-3776
+        res.vertices2d = orthographic_project_to_pixels(out.vertices, cam, config.proxy_rep_input_wh)
+    return res
+
+
+def pack_record(cam, R, betas):
+    """[cam(3) | R(216) | betas(10)] = 229 fp32 per player: the all-gather payload."""
+    B = cam.shape[0]
+    r = rt.get(cam.device)
+    rec = torch.empty((B, _abi.RECORD_FLOATS), dtype=torch.float32, device=cam.device)
+    r.check(r.lib.spsp_pack_record(r.ctx, rt.ptr(cam.contiguous()), rt.ptr(R.contiguous()), rt.ptr(betas.contiguous()), B,
+                                   rt.ptr(rec), r.stream()), 'spsp_pack_record')
+    return rec
+
+
+def unpack_record(rec):
+    B = rec.shape[0]
+    r = rt.get(rec.device)
+    cam = torch.empty((B, 3), dtype=torch.float32, device=rec.device)
+    R = torch.empty((B, 24, 3, 3), dtype=torch.float32, device=rec.device)
+    betas = torch.empty((B, 10), dtype=torch.float32, device=rec.device)
+    r.check(r.lib.spsp_unpack_record(r.ctx, rt.ptr(rec.contiguous()), B, rt.ptr(cam), rt.ptr(R), rt.ptr(betas), r.stream()),
+            'spsp_unpack_record')
+    return cam, R, betas
