@@ -57,6 +57,15 @@ void        spsp_destroy(spsp_ctx* ctx);
 const char* spsp_last_error(void);
 const char* spsp_version(void);
 
+/* ---- per-kernel timing (bench.py roofline leg): while enabled, every launch site records a HIP-event
+ *      pair on the launch stream; spsp_profile_read synchronises them, sums milliseconds and launch counts
+ *      per kernel id (a scope that issues several launches of one kernel counts as one record per launch
+ *      site) and clears the records. */
+int         spsp_profile_enable(spsp_ctx* ctx, int on);
+int         spsp_profile_num_kernels(void);
+const char* spsp_profile_kernel_name(int id);
+int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);
+
 /* ---- regressor: replaces SingleInputRegressor (PR/models/regressor.py:13-48) ------------------ */
 typedef struct {
     const float* weight;        /* host [cout,cin,k,k] fp32 (torch Conv2d layout), no bias (resnet.py:30-36) */

@@ -70,7 +70,38 @@ inline float bf16_to_f32_host(uint16_t h) {
 
 }  // namespace spsp
 
+// ---- optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg ------------
+namespace spsp {
+enum KernelId {
+    kKConv1 = 0, kKMaxpool, kKConvL1, kKConvL2, kKConvL3, kKConvL4, kKIefFc, kKIefMisc, kKProxyPack,
+    kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKNumKernels
+};
+struct ProfRec { int id; hipEvent_t start, stop; };
+}  // namespace spsp
+
 struct spsp_ctx {
     int device;
     int num_cus;
+    bool prof_on = false;
+    std::vector<spsp::ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_free;
 };
+
+namespace spsp {
+// Brackets the launches issued during its lifetime with two events when profiling is enabled.
+struct ProfScope {
+    spsp_ctx* ctx; hipStream_t st; hipEvent_t stop = nullptr;
+    ProfScope(spsp_ctx* c, int id, hipStream_t s) : ctx(c), st(s) {
+        if (!c || !c->prof_on) return;
+        hipEvent_t ev[2];
+        for (auto& e : ev) {
+            if (!c->prof_free.empty()) { e = c->prof_free.back(); c->prof_free.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) return;
+        }
+        (void)hipEventRecord(ev[0], st);
+        stop = ev[1];
+        c->prof_recs.push_back({id, ev[0], ev[1]});
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
+};
+}  // namespace spsp

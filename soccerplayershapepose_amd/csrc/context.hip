@@ -31,6 +31,42 @@ int spsp_init(int device, spsp_ctx** out) {
     return SPSP_OK;
 }
 
-void spsp_destroy(spsp_ctx* ctx) { delete ctx; }
+void spsp_destroy(spsp_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    for (auto& e : ctx->prof_free) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+static const char* const kKernelNames[spsp::kKNumKernels] = {
+    "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel", "conv_igemm_kernel<128, 64, 64, 16>",
+    "conv_igemm_kernel<128, 128, 64, 16>", "conv_igemm_kernel<64, 128, 64, 16>", "conv_igemm_kernel<64, 64, 64, 16>",
+    "fc_kernel", "init_params_kernel+split_params_kernel", "proxy_pack_kernel", "rot6d_kernel", "fit_kernel",
+    "smpl_chain_kernel", "smpl_skin_kernel", "smpl_extra_joints_kernel"};
+
+int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
+const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernelNames[id] : nullptr; }
+
+int spsp_profile_enable(spsp_ctx* ctx, int on) {
+    SPSP_REQUIRE(ctx, "spsp_profile_enable: NULL ctx");
+    ctx->prof_on = on != 0;
+    return SPSP_OK;
+}
+
+int spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches) {
+    SPSP_REQUIRE(ctx && total_ms && launches && n >= spsp::kKNumKernels, "spsp_profile_read: need %d slots", spsp::kKNumKernels);
+    for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (auto& r : ctx->prof_recs) {
+        SPSP_HIP_CHECK(hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        SPSP_HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
+        total_ms[r.id] += ms;
+        launches[r.id] += 1;
+        ctx->prof_free.push_back(r.start);
+        ctx->prof_free.push_back(r.stop);
+    }
+    ctx->prof_recs.clear();
+    return SPSP_OK;
+}
 
 }  // extern "C"

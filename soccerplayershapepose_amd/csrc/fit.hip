@@ -85,8 +85,10 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant) {
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream) {
     using namespace spsp;
-    SPSP_REQUIRE(ctx && s && cfg && R && betas && cam && joints2d, "spsp_fit: NULL argument");
+    SPSP_REQUIRE(ctx && s && cfg, "spsp_fit: NULL handle");
     SPSP_REQUIRE(B >= 0, "spsp_fit: negative batch");
+    if (B == 0) return SPSP_OK;
+    SPSP_REQUIRE(R && betas && cam && joints2d, "spsp_fit: NULL argument");
     SPSP_REQUIRE(cfg->iters >= 0 && cfg->iters <= 100000, "spsp_fit: iters=%d out of range", cfg->iters);
     SPSP_REQUIRE(cfg->loss_wh > 0.f && cfg->img_wh > 0.f, "spsp_fit: img_wh / loss_wh must be positive");
     SPSP_REQUIRE(cfg->select_mode == SPSP_FIT_SELECT_LAST || cfg->select_mode == SPSP_FIT_SELECT_BEST_L2E,
@@ -104,6 +106,7 @@ int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, 
     P.weight = std::exp(-P.log_var);
     P.select_mode = cfg->select_mode;
     P.num_levels = s->num_levels;
+    ProfScope ps(ctx, kKFit, as_stream(stream));
     fit_kernel<<<B, 64, 0, as_stream(stream)>>>(P, s->fitc, s->parents, s->level_joints, s->d_level_start,
                                                 s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist,
                                                 l2e_hist);

@@ -191,7 +191,7 @@ const int kLayerS[4] = {64, 32, 16, 8};
 const int kLayerC[4] = {64, 128, 256, 512};
 
 // conv `ci` reading map `in` (spatial Si, channels Ci, border bi) writing map `out` (spatial So, border 1)
-int run_conv(spsp_regressor* r, int ci, const uint16_t* in, int Si, int bi, uint16_t* out, const uint16_t* res, int relu,
+int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int Si, int bi, uint16_t* out, const uint16_t* res, int relu,
              int B, ConvTile tile, float* pool_out, hipStream_t st) {
     const ConvDesc& d = kConvs[ci];
     ConvArgs a;
@@ -209,6 +209,9 @@ int run_conv(spsp_regressor* r, int ci, const uint16_t* in, int Si, int bi, uint
     if (ci == 0) { a.kw_steps = 1; a.chunks = 1; a.nsteps = 7; }
     else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
     a.relu = relu;
+    const int kid = tile == kTileConv1 ? kKConv1 : tile == kTile128x64 ? kKConvL1 : tile == kTile128x128 ? kKConvL2
+                  : tile == kTile64x128 ? kKConvL3 : kKConvL4;
+    ProfScope ps(ctx, kid, st);
     return launch_conv(a, tile, st);
 }
 
@@ -287,6 +290,7 @@ int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_
     SPSP_REQUIRE(ctx && proxy_nchw && native_out && B >= 0, "spsp_proxy_pack: bad arguments");
     if (B == 0) return SPSP_OK;
     dim3 grid((kWHp + 63) / 64, kWHp, B);
+    ProfScope ps(ctx, kKProxyPack, as_stream(stream));
     proxy_pack_kernel<<<grid, 64, 0, as_stream(stream)>>>(proxy_nchw, static_cast<uint16_t*>(native_out));
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
@@ -294,7 +298,9 @@ int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_
 
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, float* cam,
                            float* pose6d, float* betas, float* feats, void* stream) {
-    SPSP_REQUIRE(ctx && r && proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
+    SPSP_REQUIRE(ctx && r, "spsp_regressor_forward: NULL handle");
+    if (B == 0) return SPSP_OK;
+    SPSP_REQUIRE(proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
     SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_forward: B=%d exceeds max_batch=%d", B, r->max_batch);
     SPSP_REQUIRE(proxy_format == SPSP_PROXY_NCHW_F32 || proxy_format == SPSP_PROXY_NATIVE,
                  "spsp_regressor_forward: unknown proxy_format %d", proxy_format);
@@ -308,9 +314,10 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         x0 = r->x0;
     }
     // stem
-    TRY(run_conv(r, 0, x0, kWH, kPad, r->c1, nullptr, 1, B, kTileConv1, nullptr, st));
+    TRY(run_conv(ctx, r, 0, x0, kWH, kPad, r->c1, nullptr, 1, B, kTileConv1, nullptr, st));
     {
         const size_t total = (size_t)B * 64 * 64 * 8;
+        ProfScope ps(ctx, kKMaxpool, st);
         maxpool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(r->c1, r->p1, B, 64, 64, 64);
         SPSP_HIP_CHECK(hipGetLastError());
     }
@@ -325,21 +332,21 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         ConvTile tile = L == 0 ? kTile128x64 : L == 1 ? (B * 8 >= 256 ? kTile128x128 : kTile64x128) : L == 2 ? kTile64x128 : kTile64x64;
         uint16_t *ba = r->l[L][0], *bb = r->l[L][1], *bc = r->l[L][2];
         if (L == 0) {
-            TRY(run_conv(r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   = relu(bn1(conv1(x)))
-            TRY(run_conv(r, ci + 1, ba, S, 1, bb, x, 1, B, tile, nullptr, st));              // out = relu(bn2(conv2(t)) + x)
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   = relu(bn1(conv1(x)))
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, x, 1, B, tile, nullptr, st));              // out = relu(bn2(conv2(t)) + x)
             ci += 2;
-            TRY(run_conv(r, ci, bb, S, 1, ba, nullptr, 1, B, tile, nullptr, st));
-            TRY(run_conv(r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));
+            TRY(run_conv(ctx, r, ci, bb, S, 1, ba, nullptr, 1, B, tile, nullptr, st));
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));
             ci += 2;
             x = bc;
         } else {
-            TRY(run_conv(r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   (stride 2)
-            TRY(run_conv(r, ci + 2, x, xs, 1, bb, nullptr, 0, B, tile, nullptr, st));        // identity = downsample(x)
-            TRY(run_conv(r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));             // out -> bc
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   (stride 2)
+            TRY(run_conv(ctx, r, ci + 2, x, xs, 1, bb, nullptr, 0, B, tile, nullptr, st));        // identity = downsample(x)
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));             // out -> bc
             ci += 3;
-            TRY(run_conv(r, ci, bc, S, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t
+            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t
             float* pool = (L == 3) ? r->feats : nullptr;
-            TRY(run_conv(r, ci + 1, ba, S, 1, bb, bc, 1, B, tile, pool, st));                // out -> bb (+ avg-pool)
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, tile, pool, st));                // out -> bb (+ avg-pool)
             ci += 2;
             x = bb;
         }
@@ -348,16 +355,25 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
     }
     r->last_B = B;
     // IEF (ief_module.py:48-64): params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) }
-    init_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, r->params);
+    {
+        ProfScope ps(ctx, kKIefMisc, st);
+        init_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, r->params);
+    }
     SPSP_HIP_CHECK(hipGetLastError());
     const dim3 gh((kHid + 3) / 4, (B + kFcPB - 1) / kFcPB), go((kNPar + 3) / 4, (B + kFcPB - 1) / kFcPB);
     for (int it = 0; it < r->ief_iters; ++it) {
-        fc_kernel<<<gh, 256, 0, st>>>(r->feats, kFeat, r->params, kNPar, r->fcw[0], r->fcb[0], kHid, B, 1, 0, r->h1, kHid);
-        fc_kernel<<<gh, 256, 0, st>>>(r->h1, kHid, nullptr, 0, r->fcw[1], r->fcb[1], kHid, B, 1, 0, r->h2, kHid);
-        fc_kernel<<<go, 256, 0, st>>>(r->h2, kHid, nullptr, 0, r->fcw[2], r->fcb[2], kNPar, B, 0, 1, r->params, kNPar);
+        { ProfScope ps(ctx, kKIefFc, st);
+          fc_kernel<<<gh, 256, 0, st>>>(r->feats, kFeat, r->params, kNPar, r->fcw[0], r->fcb[0], kHid, B, 1, 0, r->h1, kHid); }
+        { ProfScope ps(ctx, kKIefFc, st);
+          fc_kernel<<<gh, 256, 0, st>>>(r->h1, kHid, nullptr, 0, r->fcw[1], r->fcb[1], kHid, B, 1, 0, r->h2, kHid); }
+        { ProfScope ps(ctx, kKIefFc, st);
+          fc_kernel<<<go, 256, 0, st>>>(r->h2, kHid, nullptr, 0, r->fcw[2], r->fcb[2], kNPar, B, 0, 1, r->params, kNPar); }
         SPSP_HIP_CHECK(hipGetLastError());
     }
-    split_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->params, B, cam, pose6d, betas);
+    {
+        ProfScope ps(ctx, kKIefMisc, st);
+        split_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->params, B, cam, pose6d, betas);
+    }
     SPSP_HIP_CHECK(hipGetLastError());
     if (feats) SPSP_HIP_CHECK(hipMemcpyAsync(feats, r->feats, (size_t)B * kFeat * sizeof(float), hipMemcpyDeviceToDevice, st));
 #undef TRY
