@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- players/sec end-to-end (backbone -> rot6d -> 50-iter pose+shape fit -> SMPL forward -> vertices)
+on synthetic 256x256 proxy crops, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of 32 crops per GPU (BASELINE.json configs[1]), inputs
+already resident in HBM in the backbone-native layout.  With N > 1 every rank processes its own 32 crops (weak
+scaling, crops shard data-parallel with no data-path collective) and the step ends with ONE RCCL all-gather of the
+packed per-player record [cam | R | betas] = 229 fp32.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BATCH_PER_GPU = 32
+FIT_ITERS = 50
+# algorithmic work per player (SURVEY 8d / BASELINE.md section 4)
+FLOP_CONV1 = 2 * 924_844_032            # conv1 7x7/2, 18 -> 64, real (unpadded) MACs
+FLOP_L1CONV = 2 * 150_994_944           # one 3x3 64->64 conv at 64x64
+FLOP_BACKBONE = 2 * 3_139_436_544
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='crops per GPU per step')
+    ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=24, help='players timed through the CPU oracle')
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, model, x_nchw, tgt, n):
+    """The oracle (restated reference path, PyTorch-CPU fp32, full SMPL.forward + autograd + Adam per fit
+    iteration) timed on this box's host cores over a bounded sample.  Checker timed as a BASELINE only."""
+    from soccerplayershapepose_amd import synthetic as S
+    from oracle import regressor as OR, geometry as G, fit as OF, smpl as OS
+    threads = torch.get_num_threads()
+    osmpl = OS.OracleSMPL(model)
+    n = min(n, x_nchw.shape[0])
+    t0 = time.perf_counter()
+    cam, pose, shape = OR.regressor_forward(sd, x_nchw[:n], S.mean_params())
+    R = G.rot6d_to_rotmat(pose).view(n, 24, 3, 3)
+    t1 = time.perf_counter()
+    for i in range(n):
+        r = OF.fit_pose_shape(osmpl, R[i:i + 1, 1:], R[i:i + 1, :1], shape[i:i + 1], tgt[i], cam[i:i + 1], iters=FIT_ITERS)
+        body, Gm, be, ca, _ = r['last']
+        with torch.no_grad():
+            osmpl(body_pose=body, global_orient=Gm, betas=be)
+    t2 = time.perf_counter()
+    return {'value': n / (t2 - t0), 'unit': 'players/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} players end-to-end (regressor {t1 - t0:.2f}s + {FIT_ITERS}-iter fit & SMPL {t2 - t1:.2f}s), '
+                      f'torch-CPU fp32 oracle, {threads} threads'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
+
+    from soccerplayershapepose_amd import _abi, synthetic as S
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    from soccerplayershapepose_amd.models.smpl_official import SMPL
+    from soccerplayershapepose_amd.player_recon import fit_players, pack_record
+    from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
+
+    B = args.batch
+    sd = S.regressor_state_dict(seed=0)
+    model = S.smpl_model(seed=0)
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B)
+    reg.load_state_dict(sd)
+    reg.to(dev)
+    smpl = SMPL(model, max_batch=B).to(dev)
+    r = rt.get(dev)
+
+    # ---- synthetic inputs (seed 1234 + rank), resident in HBM in the backbone-native layout ----
+    x_nchw, _ = S.proxy_crops(B, seed=1234 + rank)
+    native = reg.pack(torch.from_numpy(x_nchw).to(dev))
+    # fit targets: the regressor-initialised model, perturbed + 1 px noise; set-up, untimed
+    cam0, pose0, shape0 = reg(native)
+    R0 = rot6d_to_rotmat(pose0).view(B, 24, 3, 3)
+    R2, b2, _ = S.pose_params(B, seed=77 + rank, body_deg=8, global_deg=10)
+    Rp = torch.matmul(torch.from_numpy(R2).to(dev), R0)
+    jp = smpl(body_pose=Rp[:, 1:], global_orient=Rp[:, :1], betas=shape0 + torch.from_numpy(b2).to(dev) / 3,
+              return_verts=False).joints
+    tgt_np = S.fit_targets_from_joints(jp.cpu().numpy(), cam0.cpu().numpy() * np.array([1.1, 1, 1], np.float32),
+                                       seed=4321 + rank)
+    tgt = torch.from_numpy(tgt_np[:, :, :2]).float().to(dev).contiguous()
+    variant = {'camera': 0, 'pose_shape': 1}[args.fit]
+    gathered = torch.empty((world * B, _abi.RECORD_FLOATS), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        cam, pose6d, betas = reg(native)
+        R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
+        fit_players(smpl, R, betas, cam, tgt, variant=variant, iters=FIT_ITERS)
+        out = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, pack_record(cam, R, betas))
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides ----
+    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')      # HIP-event pair around every launch
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = elapsed.item()
+    assert torch.isfinite(out.vertices).all()
+
+    nk = r.lib.spsp_profile_num_kernels()
+    ms = (C.c_double * nk)()
+    cnt = (C.c_int * nk)()
+    r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'spsp_profile_read')
+    kernels = {}
+    for i in range(nk):
+        if cnt[i]:
+            kernels[r.lib.spsp_profile_kernel_name(i).decode()] = {'launches_per_step': cnt[i] / args.steps,
+                                                                   'avg_us': 1e3 * ms[i] / cnt[i],
+                                                                   'us_per_step': 1e3 * ms[i] / args.steps}
+
+    if rank == 0:
+        # dominant kernel = the conv_igemm instantiation with the largest time per step among those whose launches
+        # all have the same shape (conv1: 1 launch/step; layer1 3x3 convs: 4 identical launches/step)
+        cands = {'conv_igemm_kernel<128, 64, 128, 8>': FLOP_CONV1 * B, 'conv_igemm_kernel<128, 64, 64, 16>': FLOP_L1CONV * B}
+        dom = max(cands, key=lambda k: kernels.get(k, {'us_per_step': 0})['us_per_step'])
+        achieved = cands[dom] / (kernels[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels else None
+        conv_us = sum(v['us_per_step'] for k, v in kernels.items() if k.startswith('conv_igemm'))
+        pmc_path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        traffic = None
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get(dom)
+        line = {
+            'metric': 'players/sec end-to-end (backbone+SMPL+fit) on 256x256 crops',
+            'value': world * B * args.steps / elapsed, 'unit': 'players/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'batch-{B} 256x256 synthetic proxy crops per GPU: ResNet-18+IEF regressor (bf16 MFMA, '
+                                   f'fp32 accumulate) -> rot6d -> {FIT_ITERS}-iter {args.fit} Adam fit -> SMPL forward '
+                                   f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
+                       'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
+                       'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,262,18] resident in HBM'},
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': (achieved / MFMA_BF16_PEAK_TFLOPS) if achieved else None,
+                         'traffic': traffic,
+                         'all_convs_tflops': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12) if conv_us else None},
+            'kernels_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

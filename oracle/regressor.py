@@ -63,9 +63,12 @@ def encoder_forward(sd, x, emulate_bf16=False, return_stages=False):
             out = _conv_bn(sd, out, blk + 'conv2', blk + 'bn2', 1, 1, emulate_bf16)
             if (blk + 'downsample.0.weight') in sd:
                 identity = q(_conv_bn(sd, x, blk + 'downsample.0', blk + 'downsample.1', stride, 0, emulate_bf16))
-            x = q(F.relu(out + identity))
+            pre = F.relu(out + identity)
+            x = q(pre)
         stages[f'layer{li}'] = x
-    feats = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
+    # the HIP backbone fuses the global average pool into the last conv's epilogue: it averages the fp32
+    # values BEFORE they are rounded to bf16 for storage (`pre`; identical to x in fp32 mode)
+    feats = torch.flatten(F.adaptive_avg_pool2d(pre, (1, 1)), 1)
     return (feats, stages) if return_stages else feats
 
 

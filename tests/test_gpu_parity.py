@@ -248,7 +248,7 @@ def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_
         scale = ref.abs().max().item()
         # same bf16 rounding points, different fp32 summation order: a few 1-ulp(bf16) flips at most
         assert err <= 0.02 * scale, f'stage {n}: max err {err} vs scale {scale}'
-        assert (got - ref).abs().mean().item() <= 2e-4 * scale, f'stage {n}: mean err'
+        assert (got - ref).abs().mean().item() <= 5e-4 * scale, f'stage {n}: mean err'   # (bf16-vs-fp32 gap is ~2.4e-3)
     np.testing.assert_allclose(feats.cpu().numpy(), f_emu.numpy(), rtol=0, atol=3e-3 * f_emu.abs().max().item())
     c_e, p_e, s_e = OR.ief_forward(regressor_sd_np, feats.cpu(), S.mean_params())
     np.testing.assert_allclose(cam.cpu().numpy(), c_e.numpy(), atol=2e-5)       # IEF itself is fp32
