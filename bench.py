@@ -43,15 +43,17 @@ def parse():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='crops per GPU per step')
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=24, help='players timed through the CPU oracle')
+    ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
+    ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, model, x_nchw, tgt, n):
+def cpu_baseline(sd, model, x_nchw, tgt, n, threads):
     """The oracle (restated reference path, PyTorch-CPU fp32, full SMPL.forward + autograd + Adam per fit
     iteration) timed on this box's host cores over a bounded sample.  Checker timed as a BASELINE only."""
     from soccerplayershapepose_amd import synthetic as S
     from oracle import regressor as OR, geometry as G, fit as OF, smpl as OS
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     threads = torch.get_num_threads()
     osmpl = OS.OracleSMPL(model)
     n = min(n, x_nchw.shape[0])
@@ -88,6 +90,7 @@ def main():
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
     from soccerplayershapepose_amd.models.smpl_official import SMPL
     from soccerplayershapepose_amd.player_recon import fit_players, pack_record
+    from soccerplayershapepose_amd.sharding import all_gather_records
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
 
     B = args.batch
@@ -113,15 +116,15 @@ def main():
                                        seed=4321 + rank)
     tgt = torch.from_numpy(tgt_np[:, :, :2]).float().to(dev).contiguous()
     variant = {'camera': 0, 'pose_shape': 1}[args.fit]
-    gathered = torch.empty((world * B, _abi.RECORD_FLOATS), dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
+        gathered = None
         cam, pose6d, betas = reg(native)
         R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
         fit_players(smpl, R, betas, cam, tgt, variant=variant, iters=FIT_ITERS)
-        out = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+        out = smpl(full_pose=R, betas=betas, pose2rot=False)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, pack_record(cam, R, betas))
+            gathered = all_gather_records(pack_record(cam, R, betas), world * B)
         return out
 
     def barrier():
@@ -188,7 +191,7 @@ def main():
             'kernels_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_sample)
+            line['cpu_baseline'] = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_sample, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -37,9 +37,6 @@ constexpr int kPrmR = 3, kPrmBeta = 219;
 
 // fit joint i reads output joint kFitSrc[i] (PR/config.py:38); < 24: chain joint, >= 24: face vertex (idx-24)
 #define SPSP_FIT_SRC {24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7, 8}
-// inverse maps: chain joint k -> fit joint (or -1); face vertex v -> fit joint
-#define SPSP_FIT_OF_JOINT {-1, 11, 12, -1, 13, 14, -1, 15, 16, -1, -1, -1, -1, -1, -1, -1, 5, 6, 7, 8, 9, 10, -1, -1}
-#define SPSP_FIT_OF_FACE {0, 2, 1, 4, 3}
 
 struct FitParams {           // kernel arguments (plain data)
     int iters;
@@ -63,6 +60,9 @@ struct FitShared {
     float part[64];
     float part2[64];
     float g[34];
+    float ga[72];            // dL/d(tw_k) seeds of the chain joints that are fit targets (others stay 0; z stays 0)
+    float h[16];             // dL/d(x_v) of the 5 face vertices (z stays 0)
+    int fit_src[17];         // fit joint i reads output joint fit_src[i] (PR/config.py:38)
     float rpart[17 * 5];     // per-fit-joint partials: loss, l2e, gs, gtx, gty
     float red[8];            // reduced: loss, l2e, gs, gtx, gty
     float adir[72], abar[72], Bbar[216];
@@ -107,6 +107,12 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
     if (lane < 26) s.level_start[lane] = level_start[lane];
     if (lane < 25) s.child_start[lane] = child_start[lane];
     if (lane == 0) { s.best_l2e = INFINITY; s.take_best = 0; }
+    {
+        const int src_tab[17] = SPSP_FIT_SRC;
+        if (lane < 17) s.fit_src[lane] = src_tab[lane];
+        for (int i = lane; i < 72; i += 64) s.ga[i] = 0.f;
+        if (lane < 16) s.h[lane] = 0.f;
+    }
     for (int q = 0; q < 4; ++q) r.m[q] = r.v[q] = 0.f;
 }
 
@@ -117,7 +123,7 @@ SPSP_HD void fit_p1(FitShared& s, int lane) {
     const float* beta = s.prm + kPrmBeta;
     for (int o = lane; o < 72; o += 64) {
         float acc = s.fc[kFcJbar + o];
-        for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcJS + i * 72 + o], beta[i], acc);
+        for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcJS + i * kJSPitch + o], beta[i], acc);
         s.J[o] = acc;
     }
     const int q = lane >> 4, c = lane & 15;
@@ -125,13 +131,13 @@ SPSP_HD void fit_p1(FitShared& s, int lane) {
     if (c < 15) {
         if (q == 0) {
             acc = s.fc[kFcVt5 + c];
-            for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcS5 + i * 16 + c], beta[i], acc);
+            for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcS5 + i * kF5Pitch + c], beta[i], acc);
         }
         const int j0 = q * 52, j1 = (j0 + 52 < kNP) ? j0 + 52 : kNP;
         for (int j = j0; j < j1; ++j) {
             const int e = j % 9;
             const float f = s.prm[kPrmR + 9 + j] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
-            acc = fmaf(s.fc[kFcP5 + j * 16 + c], f, acc);
+            acc = fmaf(s.fc[kFcP5 + j * kF5Pitch + c], f, acc);
         }
     }
     s.part[lane] = acc;
@@ -195,8 +201,7 @@ SPSP_HD void fit_p5(FitShared& s, int lane) {
 //     n = 2 px / loss_wh - 1 on both sides, L = mean(d^2) * w + lv  (multi_task_loss.py:97-113).
 SPSP_HD void fit_p6(FitShared& s, int lane, const FitParams& P) {
     if (lane >= 17) return;
-    const int src_tab[17] = SPSP_FIT_SRC;
-    const int src = src_tab[lane];
+    const int src = s.fit_src[lane];
     float X[2];
     if (src < 24) { X[0] = s.W[src * 12 + 3]; X[1] = s.W[src * 12 + 7]; }
     else { X[0] = s.xf[(src - 24) * 3]; X[1] = s.xf[(src - 24) * 3 + 1]; }
@@ -218,6 +223,8 @@ SPSP_HD void fit_p6(FitShared& s, int lane, const FitParams& P) {
         l2 = fmaf(dp, dp, l2);
         const float gu = coef * d * dn_du;                   // dL/du
         s.g[lane * 2 + c] = gu * sc;                         // dL/dX_c
+        if (src < 24) s.ga[src * 3 + c] = gu * sc;           // seeds of the reverse sweep
+        else s.h[(src - 24) * 3 + c] = gu * sc;
         gs = fmaf(gu, X[c] + t, gs);
         gt[c] = gu * sc;
     }
@@ -226,10 +233,7 @@ SPSP_HD void fit_p6(FitShared& s, int lane, const FitParams& P) {
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
-SPSP_HD float fit_h(const FitShared& s, int v, int i) {      // adjoint of face vertex v, component i (z: 0)
-    const int of_face[5] = SPSP_FIT_OF_FACE;
-    return i < 2 ? s.g[of_face[v] * 2 + i] : 0.f;
-}
+SPSP_HD float fit_h(const FitShared& s, int v, int i) { return s.h[v * 3 + i]; }   // adjoint of face vertex v
 
 // P7: reductions of P6 (lanes 0..4); direct adjoints a_k, B_k; dvp partials; direct dJ.
 SPSP_HD void fit_p7(FitShared& s, int lane) {
@@ -238,10 +242,9 @@ SPSP_HD void fit_p7(FitShared& s, int lane) {
         for (int i = 0; i < 17; ++i) acc += s.rpart[i * 5 + lane];
         s.red[lane] = acc;
     }
-    const int of_joint[24] = SPSP_FIT_OF_JOINT;
     for (int it = lane; it < 72; it += 64) {                 // item (k, i)
         const int k = it / 3, i = it % 3;
-        float a = (i < 2 && of_joint[k] >= 0) ? s.g[of_joint[k] * 2 + i] : 0.f;
+        float a = s.ga[it];
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
         for (int v = 0; v < 5; ++v) {
             const float wh = s.fc[kFcW5 + v * 24 + k] * fit_h(s, v, i);
@@ -325,7 +328,7 @@ SPSP_HD void fit_p10(FitShared& s, int lane) {
             acc = Wp[l] * s.Bbar[k * 9 + c];
             acc = fmaf(Wp[4 + l], s.Bbar[k * 9 + 3 + c], acc);
             acc = fmaf(Wp[8 + l], s.Bbar[k * 9 + 6 + c], acc);
-            const float* P5 = s.fc + kFcP5 + ((k - 1) * 9 + e) * 16;
+            const float* P5 = s.fc + kFcP5 + ((k - 1) * 9 + e) * kF5Pitch;
             for (int o = 0; o < 15; ++o) acc = fmaf(P5[o], s.dvp[o], acc);
         }
         s.grad[kPrmR + it] = acc;
@@ -352,8 +355,8 @@ SPSP_HD void fit_p11(FitShared& s, int lane) {
     float acc = 0.f;
     if (i < 10) {
         for (int o = q * 22; o < q * 22 + 22 && o < 87; ++o)
-            acc = (o < 15) ? fmaf(s.fc[kFcS5 + i * 16 + o], s.dvp[o], acc)
-                           : fmaf(s.fc[kFcJS + i * 72 + (o - 15)], s.dJt[o - 15], acc);
+            acc = (o < 15) ? fmaf(s.fc[kFcS5 + i * kF5Pitch + o], s.dvp[o], acc)
+                           : fmaf(s.fc[kFcJS + i * kJSPitch + (o - 15)], s.dJt[o - 15], acc);
     }
     s.part[lane] = acc;
 }

@@ -107,44 +107,58 @@ __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __rest
 
 // ---- IEF fully-connected layer (fp32): out[b][n] = act(bias[n] + sum_k x[b][k] W[n][k]) (+ out, if accumulate)
 // The input row is the concatenation [x0[b][0:K0] | x1[b][0:K1]] (torch.cat([feat, params]), ief_module.py:55,59).
-// One wave per output neuron and group of 8 players; lanes stride over k (coalesced weight-row reads).
-constexpr int kFcPB = 8;
-__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x0, int K0, const float* __restrict__ x1, int K1,
+// Workgroup = 4 waves = 8 neurons x 8 players: the 8 input rows are staged in LDS once (coalesced), each wave
+// streams the weight rows of its 2 neurons (lanes stride over k, all loads of a row in flight together) and
+// reduces over lanes.  Latency-bound (9 dependent launches per forward); fp32 VALU keeps the regressor outputs
+// at reference precision downstream of the bf16 backbone.
+constexpr int kFcPB = 8, kFcNPW = 2, kFcNB = 4 * kFcNPW;
+template <int K0, int K1>
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                  const float* __restrict__ W, const float* __restrict__ bias, int N, int B,
                                                  int relu, int accumulate, float* __restrict__ out, int out_stride) {
+    constexpr int K = K0 + K1, KI = (K + 63) / 64;
+    __shared__ float xs[kFcPB][K + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wave;
     const int b0 = blockIdx.y * kFcPB;
-    if (n >= N) return;
-    const int K = K0 + K1;
-    const float* wr = W + (size_t)n * K;
-    float acc[kFcPB];
+    for (int i = threadIdx.x; i < kFcPB * K; i += 256) {
+        const int p = i / K, k = i - p * K;
+        const int b = min(b0 + p, B - 1);
+        xs[p][k] = k < K0 ? x0[(size_t)b * K0 + k] : x1[(size_t)b * K1 + (k - K0)];
+    }
+    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < kFcPB; ++p) acc[p] = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float w = wr[k];
+    for (int q = 0; q < kFcNPW; ++q) {
+        const int n = blockIdx.x * kFcNB + wave * kFcNPW + q;
+        if (n >= N) break;
+        const float* wr = W + (size_t)n * K;
+        float w[KI];
+#pragma unroll
+        for (int i = 0; i < KI; ++i) { const int k = lane + 64 * i; w[i] = k < K ? wr[k] : 0.f; }
+        float acc[kFcPB];
+#pragma unroll
+        for (int p = 0; p < kFcPB; ++p) acc[p] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int k = min(lane + 64 * i, K - 1);
+#pragma unroll
+            for (int p = 0; p < kFcPB; ++p) acc[p] = fmaf(w[i], xs[p][k], acc[p]);
+        }
 #pragma unroll
         for (int p = 0; p < kFcPB; ++p) {
-            const int b = min(b0 + p, B - 1);
-            const float xv = k < K0 ? x0[(size_t)b * K0 + k] : x1[(size_t)b * K1 + (k - K0)];
-            acc[p] = fmaf(w, xv, acc[p]);
+            float v = acc[p];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            acc[p] = v;
         }
-    }
+        if (lane < kFcPB && b0 + lane < B) {
+            float v = 0.f;
 #pragma unroll
-    for (int p = 0; p < kFcPB; ++p) {
-        float v = acc[p];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[p] = v;
-    }
-    if (lane < kFcPB && b0 + lane < B) {
-        float v = 0.f;
-#pragma unroll
-        for (int p = 0; p < kFcPB; ++p) v = (lane == p) ? acc[p] : v;
-        v += bias[n];
-        if (relu) v = fmaxf(v, 0.f);
-        float* o = out + (size_t)(b0 + lane) * out_stride + n;
-        *o = accumulate ? (*o + v) : v;
+            for (int p = 0; p < kFcPB; ++p) v = (lane == p) ? acc[p] : v;
+            v += bias[n];
+            if (relu) v = fmaxf(v, 0.f);
+            float* o = out + (size_t)(b0 + lane) * out_stride + n;
+            *o = accumulate ? (*o + v) : v;
+        }
     }
 }
 
@@ -360,14 +374,14 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         init_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, r->params);
     }
     SPSP_HIP_CHECK(hipGetLastError());
-    const dim3 gh((kHid + 3) / 4, (B + kFcPB - 1) / kFcPB), go((kNPar + 3) / 4, (B + kFcPB - 1) / kFcPB);
+    const dim3 gh((kHid + kFcNB - 1) / kFcNB, (B + kFcPB - 1) / kFcPB), go((kNPar + kFcNB - 1) / kFcNB, (B + kFcPB - 1) / kFcPB);
     for (int it = 0; it < r->ief_iters; ++it) {
         { ProfScope ps(ctx, kKIefFc, st);
-          fc_kernel<<<gh, 256, 0, st>>>(r->feats, kFeat, r->params, kNPar, r->fcw[0], r->fcb[0], kHid, B, 1, 0, r->h1, kHid); }
+          fc_kernel<kFeat, kNPar><<<gh, 256, 0, st>>>(r->feats, r->params, r->fcw[0], r->fcb[0], kHid, B, 1, 0, r->h1, kHid); }
         { ProfScope ps(ctx, kKIefFc, st);
-          fc_kernel<<<gh, 256, 0, st>>>(r->h1, kHid, nullptr, 0, r->fcw[1], r->fcb[1], kHid, B, 1, 0, r->h2, kHid); }
+          fc_kernel<kHid, 0><<<gh, 256, 0, st>>>(r->h1, nullptr, r->fcw[1], r->fcb[1], kHid, B, 1, 0, r->h2, kHid); }
         { ProfScope ps(ctx, kKIefFc, st);
-          fc_kernel<<<go, 256, 0, st>>>(r->h2, kHid, nullptr, 0, r->fcw[2], r->fcb[2], kNPar, B, 0, 1, r->params, kNPar); }
+          fc_kernel<kHid, 0><<<go, 256, 0, st>>>(r->h2, nullptr, r->fcw[2], r->fcb[2], kNPar, B, 0, 1, r->params, kNPar); }
         SPSP_HIP_CHECK(hipGetLastError());
     }
     {

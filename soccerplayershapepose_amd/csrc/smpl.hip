@@ -20,7 +20,7 @@
 namespace {
 using namespace spsp;
 
-constexpr int kSkinThreads = 128;
+constexpr int kSkinThreads = 256;
 constexpr int kPB = 8;   // players per skin workgroup
 
 __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ R, const float* __restrict__ betas,
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
     }
 }
 
+// Workgroup = 4 waves over the SAME 64 vertices and 8 players: wave w accumulates rows [55w, 55w+55) of the
+// 217-row blend basis (split-K: 4x more waves and 4x shorter dependent-load chains at no extra basis traffic),
+// partial sums meet in LDS, then wave w skins players 2w and 2w+1.
 __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __restrict__ basis,
                                                                  const float* __restrict__ v_template,
                                                                  const float* __restrict__ wT,
@@ -69,7 +72,9 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
                                                                  const float* __restrict__ coef, int B,
                                                                  float* __restrict__ verts) {
     __shared__ float sCoef[kPB][kNCoef + 3];
-    __shared__ float sA[kPB][288];
+    __shared__ __attribute__((aligned(16))) float sA[kPB][288];
+    __shared__ float sPart[4][kPB * 3][64];                // [k-slice][player*3 + c][lane]
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int b0 = blockIdx.y * kPB;
     const int nb = min(kPB, B - b0);
     for (int i = threadIdx.x; i < kPB * kNCoef; i += kSkinThreads) {
@@ -81,17 +86,15 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
         sA[p][j] = (p < nb) ? A[(size_t)(b0 + p) * 288 + j] : 0.f;
     }
     __syncthreads();
-    const int v = blockIdx.x * kSkinThreads + threadIdx.x;
-    if (v >= kV) return;
+    const int v = min(blockIdx.x * 64 + lane, kV - 1);
     float px[kPB], py[kPB], pz[kPB];
-    {
-        const float t0 = v_template[3 * v], t1 = v_template[3 * v + 1], t2 = v_template[3 * v + 2];
 #pragma unroll
-        for (int p = 0; p < kPB; ++p) { px[p] = t0; py[p] = t1; pz[p] = t2; }
-    }
+    for (int p = 0; p < kPB; ++p) px[p] = py[p] = pz[p] = 0.f;
+    constexpr int kRows = (kNCoef + 3) / 4;                 // 55 rows per slice (last slice: 52)
+    const int j0 = ks * kRows, j1 = min(j0 + kRows, kNCoef);
     const float* bp = basis + 3 * v;
-#pragma unroll 4
-    for (int j = 0; j < kNCoef; ++j) {
+#pragma unroll 5
+    for (int j = j0; j < j1; ++j) {
         const float d0 = bp[(size_t)j * kV3], d1 = bp[(size_t)j * kV3 + 1], d2 = bp[(size_t)j * kV3 + 2];
 #pragma unroll
         for (int p = 0; p < kPB; ++p) {
@@ -101,28 +104,46 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
             pz[p] = fmaf(c, d2, pz[p]);
         }
     }
-    // T = sum_k w[v][k] A_k (3x4), vert = T [v_posed; 1]
-    float ox[kPB], oy[kPB], oz[kPB];
 #pragma unroll
-    for (int p = 0; p < kPB; ++p) ox[p] = oy[p] = oz[p] = 0.f;
+    for (int p = 0; p < kPB; ++p) {
+        sPart[ks][p * 3 + 0][lane] = px[p];
+        sPart[ks][p * 3 + 1][lane] = py[p];
+        sPart[ks][p * 3 + 2][lane] = pz[p];
+    }
+    __syncthreads();
+    // skinning: this wave takes players 2*ks, 2*ks+1.  T = sum_k w[v][k] A_k (3x4), vert = T [v_posed; 1]
+    const bool vok = blockIdx.x * 64 + lane < kV;
+    float qx[2], qy[2], qz[2], ox[2], oy[2], oz[2];
+    const float t0 = v_template[3 * v], t1 = v_template[3 * v + 1], t2 = v_template[3 * v + 2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = ks * 2 + q;
+        qx[q] = t0 + ((sPart[0][p * 3][lane] + sPart[1][p * 3][lane]) + (sPart[2][p * 3][lane] + sPart[3][p * 3][lane]));
+        qy[q] = t1 + ((sPart[0][p * 3 + 1][lane] + sPart[1][p * 3 + 1][lane]) + (sPart[2][p * 3 + 1][lane] + sPart[3][p * 3 + 1][lane]));
+        qz[q] = t2 + ((sPart[0][p * 3 + 2][lane] + sPart[1][p * 3 + 2][lane]) + (sPart[2][p * 3 + 2][lane] + sPart[3][p * 3 + 2][lane]));
+        ox[q] = oy[q] = oz[q] = 0.f;
+    }
+#pragma unroll 4
     for (int k = 0; k < kNJ; ++k) {
         const float w = wT[(size_t)k * kV + v];
 #pragma unroll
-        for (int p = 0; p < kPB; ++p) {
-            const float* a = &sA[p][k * 12];
-            const float rx = fmaf(a[0], px[p], fmaf(a[1], py[p], fmaf(a[2], pz[p], a[3])));
-            const float ry = fmaf(a[4], px[p], fmaf(a[5], py[p], fmaf(a[6], pz[p], a[7])));
-            const float rz = fmaf(a[8], px[p], fmaf(a[9], py[p], fmaf(a[10], pz[p], a[11])));
-            ox[p] = fmaf(w, rx, ox[p]);
-            oy[p] = fmaf(w, ry, oy[p]);
-            oz[p] = fmaf(w, rz, oz[p]);
+        for (int q = 0; q < 2; ++q) {
+            const float4* a = reinterpret_cast<const float4*>(&sA[ks * 2 + q][k * 12]);
+            const float4 r0 = a[0], r1 = a[1], r2 = a[2];
+            const float rx = fmaf(r0.x, qx[q], fmaf(r0.y, qy[q], fmaf(r0.z, qz[q], r0.w)));
+            const float ry = fmaf(r1.x, qx[q], fmaf(r1.y, qy[q], fmaf(r1.z, qz[q], r1.w)));
+            const float rz = fmaf(r2.x, qx[q], fmaf(r2.y, qy[q], fmaf(r2.z, qz[q], r2.w)));
+            ox[q] = fmaf(w, rx, ox[q]);
+            oy[q] = fmaf(w, ry, oy[q]);
+            oz[q] = fmaf(w, rz, oz[q]);
         }
     }
 #pragma unroll
-    for (int p = 0; p < kPB; ++p) {
-        if (p < nb) {
+    for (int q = 0; q < 2; ++q) {
+        const int p = ks * 2 + q;
+        if (p < nb && vok) {
             float* o = verts + ((size_t)(b0 + p) * kV + v) * 3;
-            o[0] = ox[p]; o[1] = oy[p]; o[2] = oz[p];
+            o[0] = ox[q]; o[1] = oy[q]; o[2] = oz[q];
         }
     }
 }
@@ -216,7 +237,7 @@ int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
                                         s->num_levels, s->ws_A, s->ws_coef, joints); }
     SPSP_HIP_CHECK(hipGetLastError());
     float* v = verts ? verts : s->ws_verts;
-    dim3 grid((kV + kSkinThreads - 1) / kSkinThreads, (B + kPB - 1) / kPB);
+    dim3 grid((kV + 63) / 64, (B + kPB - 1) / kPB);
     { ProfScope ps(ctx, kKSmplSkin, st);
       smpl_skin_kernel<<<grid, kSkinThreads, 0, st>>>(s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v); }
     SPSP_HIP_CHECK(hipGetLastError());

@@ -13,14 +13,16 @@ constexpr int kNP = SPSP_NUM_POSE_BASIS;    // 207
 constexpr int kNCoef = kNB + kNP;           // 217 rows of the blend basis: [betas | R[1:]-I]
 constexpr int kNFace = 5;                   // picked vertices that feed the 17 fit joints (nose, eyes, ears)
 
-// Fit constants, one contiguous fp32 block copied into LDS by every fit workgroup.
-// Offsets in floats.  P5 rows are padded to 16 so (j, c) -> j*16 + c.
-constexpr int kFcJbar = 0;                       // [24][3]
-constexpr int kFcJS = kFcJbar + 72;              // [10][72]   JS[i][k*3+c]
-constexpr int kFcVt5 = kFcJS + 720;              // [16]       template coords of the 5 face verts (15 used)
-constexpr int kFcS5 = kFcVt5 + 16;               // [10][16]   shapedirs rows of the 5 face verts
-constexpr int kFcP5 = kFcS5 + 160;               // [207][16]  posedirs columns of the 5 face verts
-constexpr int kFcW5 = kFcP5 + 207 * 16;          // [5][24]    lbs weights of the 5 face verts
-constexpr int kFcTotal = kFcW5 + 120;            // 4400 floats = 17.6 KB
+// Fit constants, one contiguous fp32 block copied into LDS by every fit workgroup.  Offsets in floats.
+// Row pitches are ODD (73 / 17) so that both access patterns of the fit kernel -- lanes along a row and lanes
+// along a column -- spread over distinct LDS banks.
+constexpr int kJSPitch = 73, kF5Pitch = 17;
+constexpr int kFcJbar = 0;                                // [24][3]
+constexpr int kFcJS = kFcJbar + 72;                       // [10][73]   JS[i][k*3+c]
+constexpr int kFcVt5 = kFcJS + 10 * kJSPitch;             // [16]       template coords of the 5 face verts (15 used)
+constexpr int kFcS5 = kFcVt5 + 16;                        // [10][17]   shapedirs rows of the 5 face verts
+constexpr int kFcP5 = kFcS5 + 10 * kF5Pitch;              // [207][17]  posedirs columns of the 5 face verts
+constexpr int kFcW5 = kFcP5 + 207 * kF5Pitch;             // [5][24]    lbs weights of the 5 face verts
+constexpr int kFcTotal = kFcW5 + 120;                     // 4627 floats = 18.5 KB
 
 }  // namespace spsp

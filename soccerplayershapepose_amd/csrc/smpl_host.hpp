@@ -106,14 +106,16 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
     }
     // fit constants (face vertices = first 5 picked ids: nose, reye, leye, rear, lear)
     h.fitc.assign(kFcTotal, 0.f);
-    std::memcpy(h.fitc.data() + kFcJbar, h.jconst.data(), sizeof(float) * 792);
+    std::memcpy(h.fitc.data() + kFcJbar, h.jconst.data(), sizeof(float) * 72);
+    for (int i = 0; i < kNB; ++i)
+        std::memcpy(h.fitc.data() + kFcJS + i * kJSPitch, h.jconst.data() + 72 + i * 72, sizeof(float) * 72);
     for (int f = 0; f < kNFace; ++f) {
         const int v = a.vertex_joint_ids[f];
         h.face_ids[f] = v;
         for (int c = 0; c < 3; ++c) {
             h.fitc[kFcVt5 + f * 3 + c] = a.v_template[3 * v + c];
-            for (int i = 0; i < kNB; ++i) h.fitc[kFcS5 + i * 16 + f * 3 + c] = a.shapedirs[((size_t)v * 3 + c) * kNB + i];
-            for (int j = 0; j < kNP; ++j) h.fitc[kFcP5 + j * 16 + f * 3 + c] = a.posedirs[(size_t)j * kV3 + 3 * v + c];
+            for (int i = 0; i < kNB; ++i) h.fitc[kFcS5 + i * kF5Pitch + f * 3 + c] = a.shapedirs[((size_t)v * 3 + c) * kNB + i];
+            for (int j = 0; j < kNP; ++j) h.fitc[kFcP5 + j * kF5Pitch + f * 3 + c] = a.posedirs[(size_t)j * kV3 + 3 * v + c];
         }
         for (int k = 0; k < kNJ; ++k) h.fitc[kFcW5 + f * 24 + k] = a.lbs_weights[(size_t)v * kNJ + k];
     }

@@ -106,7 +106,9 @@ class SMPL:
         return torch.cat([go, bp], dim=1).contiguous(), bp, go
 
     def forward(self, body_pose=None, global_orient=None, betas=None, pose2rot=False, get_skin=True,
-                return_verts=True, return_joints=True):
+                return_verts=True, return_joints=True, full_pose=None):
+        """`full_pose` [B,24,3,3] (contiguous CUDA fp32) may be given instead of body_pose + global_orient: it is
+        used as is, without the torch.cat the reference-style arguments need."""
         if pose2rot and (body_pose is not None or global_orient is not None):
             raise NotImplementedError('axis-angle input (pose2rot=True) is not on the hot path: the reference always '
                                       'passes rotation matrices (PR/PyTorch3DTest.py:3082, PR/player_recon.py:1207)')
@@ -120,7 +122,11 @@ class SMPL:
         B = betas.shape[0]
         if B > self.max_batch:
             raise ValueError(f'SMPL.forward: batch {B} exceeds max_batch {self.max_batch}')
-        full_pose, bp, go = self.full_pose_from(body_pose, global_orient, B, r.device)
+        if full_pose is not None:
+            full_pose = rt.dev_f32(full_pose, r.device).reshape(B, 24, 3, 3)
+            bp, go = full_pose[:, 1:], full_pose[:, :1]
+        else:
+            full_pose, bp, go = self.full_pose_from(body_pose, global_orient, B, r.device)
         verts = torch.empty((B, 6890, 3), dtype=torch.float32, device=r.device) if return_verts else None
         joints = torch.empty((B, 90, 3), dtype=torch.float32, device=r.device) if return_joints else None
         r.check(r.lib.spsp_smpl_forward(r.ctx, self.handle, rt.ptr(full_pose), rt.ptr(betas), B, rt.ptr(verts),

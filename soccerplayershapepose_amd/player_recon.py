@@ -103,7 +103,7 @@ def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape
     if fit is not None:
         variant = {'camera': 0, 'pose_shape': 1}[fit]
         fit_players(smpl, R, betas, cam, joints2D, variant=variant, iters=iters, lr=lr, select_mode=select_mode)
-    out = smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False)
+    out = smpl(full_pose=R, betas=betas, pose2rot=False)
     res = SimpleNamespace(cam=cam, rotmats=R, betas=betas, vertices=out.vertices, joints=out.joints,
                           translation=convert_weak_perspective_to_camera_translation_torch(
                               cam, config.FOCAL_LENGTH, config.proxy_rep_input_wh))

@@ -1,0 +1,45 @@
+"""Data-parallel sharding of player crops over the ranks of one node + the single exchange step.
+
+The reference has no distributed path at all; this is new design: every player is an
+independent unit, so crops shard in contiguous blocks with NO data-path collective, and the only exchange is one
+all-gather of the packed per-player record [cam(3) | R(216) | betas(10)] (916 B/player) after the fit --
+`torch.distributed` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  The message is tens of
+KB per rank: latency-bound, so it is ONE collective on equal-sized padded blocks, not a ring of small sends."""
+import torch
+import torch.distributed as dist
+
+
+def shard_sizes(n, world):
+    """Contiguous split of n players over `world` ranks, sizes differing by at most one (22 players on 8 ranks ->
+    3,3,3,3,3,3,2,2)."""
+    q, r = divmod(n, world)
+    return [q + 1 if i < r else q for i in range(world)]
+
+
+def shard_range(n, world, rank):
+    sizes = shard_sizes(n, world)
+    start = sum(sizes[:rank])
+    return start, start + sizes[rank]
+
+
+def all_gather_records(local, n_total, group=None):
+    """local: [n_local, 229] records of this rank's shard (shard_range order) -> [n_total, 229] on every rank.
+    Ragged shards are padded to the largest shard so a single all_gather_into_tensor suffices."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    sizes = shard_sizes(n_total, world)
+    rank = dist.get_rank(group)
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f'rank {rank}: got {local.shape[0]} records, shard_sizes says {sizes[rank]}')
+    width = local.shape[1]
+    m = max(sizes)
+    padded = local
+    if local.shape[0] < m:
+        padded = torch.zeros((m, width), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    out = torch.empty((world * m, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(s == m for s in sizes):
+        return out
+    return torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)

@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/spsp.h declares; host-side logic of the Python
+mirror; the product fails loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from soccerplayershapepose_amd import _abi, synthetic as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'spsp.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(spsp_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 25
+    lib = _abi.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f'{sym} declared in include/spsp.h but not exported by libspsp.so'
+    assert declared == set(_abi.EXPORTED_SYMBOLS), declared ^ set(_abi.EXPORTED_SYMBOLS)
+
+
+def test_conv_table_matches_reference_state_dict_schema(regressor_sd_np):
+    lib = _abi.load()
+    names = [lib.spsp_conv_name(i).decode() for i in range(_abi.NUM_CONVS)]
+    assert names == [t[0] for t in S.regressor_layer_table()]
+    assert lib.spsp_conv_name(20) is None and lib.spsp_conv_name(-1) is None
+    for i, n in enumerate(names):
+        bn = lib.spsp_conv_bn_name(i).decode()
+        assert n + '.weight' in regressor_sd_np and bn + '.running_var' in regressor_sd_np
+    assert len(regressor_sd_np) == 132
+
+
+def test_fit_config_defaults_mirror_reference_constants():
+    lib = _abi.load()
+    a, b = _abi.FitConfig(), _abi.FitConfig()
+    lib.spsp_fit_config_default(C.byref(a), 0)
+    lib.spsp_fit_config_default(C.byref(b), 1)
+    assert (a.iters, a.lr, a.param_mask, a.select_mode) == (50, 0.01, _abi.FIT_MASK_CAMERA, 0)      # PyTorch3DTest.py:3077-3080
+    assert (b.iters, b.lr, b.param_mask) == (50, 1e-3, _abi.FIT_MASK_POSE_SHAPE)                     # player_recon.py:1198
+    assert (a.beta1, a.beta2, a.eps, a.img_wh, a.loss_wh, a.loss_weight) == (0.9, 0.999, 1e-8, 512.0, 256.0, 1.0)
+    trainable = [k for k in range(24) if (b.param_mask >> k) & 1]
+    assert trainable == [0] + list(range(1, 7)) + list(range(9, 22))      # body_pose idx 0-5 & 8-20 (+ global orient)
+
+
+def test_profile_kernel_names_and_native_layout_size():
+    lib = _abi.load()
+    n = lib.spsp_profile_num_kernels()
+    names = [lib.spsp_profile_kernel_name(i).decode() for i in range(n)]
+    assert 'fit_kernel' in names and sum(k.startswith('conv_igemm_kernel') for k in names) == 5
+    assert lib.spsp_proxy_native_bytes() == 262 * 262 * 18 * 2
+
+
+def test_smpl_array_validation_on_host(smpl_model_np):
+    bad = dict(smpl_model_np)
+    bad['posedirs'] = smpl_model_np['posedirs'][:, :-3]
+    with pytest.raises(ValueError):
+        _abi.smpl_arrays(bad)
+    arrs, keep = _abi.smpl_arrays(smpl_model_np)
+    assert len(keep) == 10
+
+
+def test_proxy_builder_mirror_matches_oracle_and_reference_heatmaps(golden):
+    from soccerplayershapepose_amd.predict.predict_3D import create_proxy_representation
+    from soccerplayershapepose_amd.utils.label_conversions import convert_2Djoints_to_gaussian_heatmaps
+    from oracle import geometry as G
+    g = golden('geometry')
+    hm = convert_2Djoints_to_gaussian_heatmaps(g['hm_joints'], 256)
+    np.testing.assert_allclose(hm.sum(axis=(0, 1)), g['hm_sum'], rtol=1e-6)
+    sil = (S.hash_uniform(512 * 512, 'sil').reshape(512, 512) > 0.5).astype(np.float64)
+    j = np.concatenate([512 * S.hash_uniform(34, 'j').reshape(17, 2), np.ones((17, 1))], axis=1)
+    a = create_proxy_representation(sil, j, in_wh=512, out_wh=256)
+    b = G.create_proxy_representation(sil, j, 512, 256)
+    assert a.shape == (18, 256, 256) and np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        create_proxy_representation(sil, j, in_wh=512, out_wh=200)
+
+
+def test_regressor_host_checks(regressor_sd_np):
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    with pytest.raises(NotImplementedError):
+        SingleInputRegressor(1, 50, 3)
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params())
+    sd = dict(regressor_sd_np)
+    del sd['image_encoder.layer3.0.downsample.1.running_var']
+    with pytest.raises(KeyError):
+        reg.load_state_dict(sd)
+    reg.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in regressor_sd_np.items()})   # torch tensors accepted
+    assert reg.initial_params_estimate[0] == np.float32(0.9) and reg.initial_params_estimate[3] == 1.0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_fails_loudly_without_gpu(smpl_model_np):
+    from soccerplayershapepose_amd import runtime
+    from soccerplayershapepose_amd.models.smpl_official import SMPL
+    from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        runtime.get()
+    with pytest.raises(RuntimeError):
+        rot6d_to_rotmat(torch.zeros(2, 6))
+    with pytest.raises(RuntimeError):
+        SMPL(smpl_model_np)(betas=torch.zeros(1, 10))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'soccerplayershapepose_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f'{f} imports the oracle'
