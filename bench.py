@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='crops per GPU per step')
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--depth', type=int, default=2, help='pipeline slots (HIP streams); 1 = strictly serial steps')
     ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
     return ap.parse_args()
@@ -89,17 +90,22 @@ def main():
     from soccerplayershapepose_amd import runtime as rt
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
     from soccerplayershapepose_amd.models.smpl_official import SMPL
-    from soccerplayershapepose_amd.player_recon import fit_players, pack_record
+    from soccerplayershapepose_amd.player_recon import PlayerPipeline, pack_record
     from soccerplayershapepose_amd.sharding import all_gather_records
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
 
     B = args.batch
     sd = S.regressor_state_dict(seed=0)
     model = S.smpl_model(seed=0)
-    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B)
-    reg.load_state_dict(sd)
-    reg.to(dev)
-    smpl = SMPL(model, max_batch=B).to(dev)
+    def make_regressor():
+        m = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B)
+        return m.load_state_dict(sd)
+
+    def make_smpl():
+        return SMPL(model, max_batch=B)
+
+    pipe = PlayerPipeline(make_regressor, make_smpl, dev, depth=max(1, args.depth))
+    reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl
     r = rt.get(dev)
 
     # ---- synthetic inputs (seed 1234 + rank), resident in HBM in the backbone-native layout ----
@@ -115,17 +121,16 @@ def main():
     tgt_np = S.fit_targets_from_joints(jp.cpu().numpy(), cam0.cpu().numpy() * np.array([1.1, 1, 1], np.float32),
                                        seed=4321 + rank)
     tgt = torch.from_numpy(tgt_np[:, :, :2]).float().to(dev).contiguous()
-    variant = {'camera': 0, 'pose_shape': 1}[args.fit]
+    torch.cuda.synchronize()
 
     def step():
-        gathered = None
-        cam, pose6d, betas = reg(native)
-        R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
-        fit_players(smpl, R, betas, cam, tgt, variant=variant, iters=FIT_ITERS)
-        out = smpl(full_pose=R, betas=betas, pose2rot=False)
+        # one batch through the WHOLE path on the next pipeline slot (its own stream): regressor -> rot6d ->
+        # 50-iter fit -> SMPL forward [-> all-gather of the records]
+        res = pipe.submit(native, tgt, fit=args.fit, iters=FIT_ITERS)
         if world > 1:
-            gathered = all_gather_records(pack_record(cam, R, betas), world * B)
-        return out
+            with torch.cuda.stream(res.stream):
+                res.gathered = all_gather_records(pack_record(res.cam, res.rotmats, res.betas), world * B)
+        return res
 
     def barrier():
         if world > 1:
@@ -150,7 +155,7 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = elapsed.item()
-    assert torch.isfinite(out.vertices).all()
+    assert torch.isfinite(out.vertices).all() and out.vertices.abs().max().item() > 0.1
 
     nk = r.lib.spsp_profile_num_kernels()
     ms = (C.c_double * nk)()
@@ -183,7 +188,8 @@ def main():
                                    f'fp32 accumulate) -> rot6d -> {FIT_ITERS}-iter {args.fit} Adam fit -> SMPL forward '
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
-                       'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,262,18] resident in HBM'},
+                       'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,262,18] resident in HBM',
+                       'pipeline_slots': max(1, args.depth)},
             'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': (achieved / MFMA_BF16_PEAK_TFLOPS) if achieved else None,
                          'traffic': traffic,

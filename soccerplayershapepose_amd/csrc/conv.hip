@@ -50,7 +50,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+    // XCD-aware tile order (guide T1): workgroups are dealt round-robin over the 8 XCDs, each with a private
+    // 4 MB L2.  Give XCD x the x-th CONTIGUOUS eighth of the tile list (n-tile major, m-tile minor), so the
+    // workgroups sharing an L2 work on one weight panel and on neighbouring pixels (halo + 9-tap re-reads
+    // become L2 hits).  Placement only affects speed, never results.
+    const int mt = a.M / BM;
+    const int ntiles = mt * (a.N / BN);
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int m_blk = (tile % mt) * BM, n_blk = (tile / mt) * BN;
     const int HoWo = a.Ho * a.Wo;
 
     // ---- loader set-up: this thread's activation rows (fixed for the whole K loop) ----
@@ -217,7 +225,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(a.M / BM, a.N / BN);
+    dim3 grid((a.M / BM) * (a.N / BN));
     conv_igemm_kernel<BM, BN, BK, LOADB><<<grid, 256, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;

@@ -26,10 +26,16 @@ struct ConvArgs {
     int stride;
     int kw_steps, chunks, nsteps;
     int relu;
+    float* part;             // split-K: fp32 slabs [splitk][M][N] (conv_ring only)
+    int splitk;              // 1 = no split
 };
 
 enum ConvTile { kTile128x64 = 0, kTile128x128, kTile64x128, kTile64x64, kTileConv1 };
 
 int launch_conv(const ConvArgs& a, ConvTile tile, hipStream_t stream);
+
+// second generation (conv_ring.hip): LDS-DMA ring, BK = 64, optional split-K
+enum RingTile { kRing128x128s3 = 0, kRing128x128s2, kRing128x64s3, kRing128x64s4, kRing64x128s3, kRing64x64s4, kRingNone };
+int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 
 }  // namespace spsp

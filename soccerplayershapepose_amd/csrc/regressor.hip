@@ -2,6 +2,7 @@
 // MFMA implicit-GEMM convolutions (conv.hip) over zero-bordered NHWC bf16 feature maps, + the IEF MLP
 // (PR/models/ief_module.py:48-64) in fp32.  Eval-mode BatchNorm is folded into weights/bias at load.
 #include <cmath>
+#include <cstdlib>
 #include <string>
 
 #include "conv.hpp"
@@ -197,6 +198,11 @@ struct spsp_regressor {
     float *feats, *params, *h1, *h2;
     const uint16_t* stage_ptr[6];
     int last_B;
+    float* slab;           // split-K fp32 slabs
+    size_t slab_floats;
+    // per residual stage: ring tile (kRingNone = first-generation kernel) and split-K factor
+    RingTile ring[4];
+    int splitk[4];
 };
 
 namespace {
@@ -206,7 +212,7 @@ const int kLayerC[4] = {64, 128, 256, 512};
 
 // conv `ci` reading map `in` (spatial Si, channels Ci, border bi) writing map `out` (spatial So, border 1)
 int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int Si, int bi, uint16_t* out, const uint16_t* res, int relu,
-             int B, ConvTile tile, float* pool_out, hipStream_t st) {
+             int B, ConvTile tile, float* pool_out, hipStream_t st, int L = -1) {
     const ConvDesc& d = kConvs[ci];
     ConvArgs a;
     std::memset(&a, 0, sizeof a);
@@ -223,6 +229,21 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     if (ci == 0) { a.kw_steps = 1; a.chunks = 1; a.nsteps = 7; }
     else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
     a.relu = relu;
+    a.splitk = 1;
+    if (L >= 0 && r->ring[L] != kRingNone) {
+        const RingTile rt = r->ring[L];
+        const int bm = (rt == kRing64x128s3 || rt == kRing64x64s4) ? 64 : 128;
+        const int bn = (rt == kRing128x64s3 || rt == kRing128x64s4 || rt == kRing64x64s4) ? 64 : 128;
+        if (a.M % bm == 0 && a.N % bn == 0) {
+            int sk = r->splitk[L];
+            while (sk > 1 && (a.nsteps / sk < 4 || (size_t)sk * a.M * a.N > r->slab_floats)) sk >>= 1;
+            a.splitk = sk;
+            a.part = r->slab;
+            const int kid2 = L == 0 ? kKConvL1 : L == 1 ? kKConvL2 : L == 2 ? kKConvL3 : kKConvL4;
+            ProfScope ps(ctx, kid2, st);
+            return launch_conv_ring(a, rt, st);
+        }
+    }
     const int kid = tile == kTileConv1 ? kKConv1 : tile == kTile128x64 ? kKConvL1 : tile == kTile128x128 ? kKConvL2
                   : tile == kTile64x128 ? kKConvL3 : kKConvL4;
     ProfScope ps(ctx, kid, st);
@@ -289,6 +310,30 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     for (int L = 0; L < 4; ++L)
         for (int j = 0; j < 3; ++j)
             TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
+    r->slab_floats = B * 65536 * 4;
+    TRY(r->pool.alloc(&r->slab, r->slab_floats));
+    {   // conv plan for the residual stages; SPSP_CONV_PLAN="tile:splitk,tile:splitk,tile:splitk,tile:splitk"
+        // with tile in {old, r128x128s3, r128x128s2, r128x64s3, r128x64s4, r64x128s3, r64x64s4} (tuning aid)
+        const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};   // measured best at 32 crops
+        const int def_s[4] = {1, 1, 1, 1};
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->splitk[L] = def_s[L]; }
+        if (const char* env = getenv("SPSP_CONV_PLAN")) {
+            std::string e(env);
+            size_t pos = 0;
+            for (int L = 0; L < 4 && pos < e.size(); ++L) {
+                size_t end = e.find(',', pos);
+                if (end == std::string::npos) end = e.size();
+                std::string tok = e.substr(pos, end - pos);
+                pos = end + 1;
+                int sk = 1;
+                const size_t colon = tok.find(':');
+                if (colon != std::string::npos) { sk = atoi(tok.c_str() + colon + 1); tok = tok.substr(0, colon); }
+                const char* names[7] = {"r128x128s3", "r128x128s2", "r128x64s3", "r128x64s4", "r64x128s3", "r64x64s4", "old"};
+                for (int t = 0; t < 7; ++t)
+                    if (tok == names[t]) { r->ring[L] = (RingTile)t; r->splitk[L] = sk < 1 ? 1 : sk; }
+            }
+        }
+    }
     TRY(r->pool.alloc(&r->feats, B * kFeat));
     TRY(r->pool.alloc(&r->params, B * kNPar));
     TRY(r->pool.alloc(&r->h1, B * kHid));
@@ -346,21 +391,21 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         ConvTile tile = L == 0 ? kTile128x64 : L == 1 ? (B * 8 >= 256 ? kTile128x128 : kTile64x128) : L == 2 ? kTile64x128 : kTile64x64;
         uint16_t *ba = r->l[L][0], *bb = r->l[L][1], *bc = r->l[L][2];
         if (L == 0) {
-            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   = relu(bn1(conv1(x)))
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, x, 1, B, tile, nullptr, st));              // out = relu(bn2(conv2(t)) + x)
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st, L));         // t   = relu(bn1(conv1(x)))
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, x, 1, B, tile, nullptr, st, L));           // out = relu(bn2(conv2(t)) + x)
             ci += 2;
-            TRY(run_conv(ctx, r, ci, bb, S, 1, ba, nullptr, 1, B, tile, nullptr, st));
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));
+            TRY(run_conv(ctx, r, ci, bb, S, 1, ba, nullptr, 1, B, tile, nullptr, st, L));
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st, L));
             ci += 2;
             x = bc;
         } else {
-            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t   (stride 2)
-            TRY(run_conv(ctx, r, ci + 2, x, xs, 1, bb, nullptr, 0, B, tile, nullptr, st));        // identity = downsample(x)
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st));             // out -> bc
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st, L));         // t   (stride 2)
+            TRY(run_conv(ctx, r, ci + 2, x, xs, 1, bb, nullptr, 0, B, tile, nullptr, st, L));     // identity = downsample(x)
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st, L));          // out -> bc
             ci += 3;
-            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, tile, nullptr, st));            // t
+            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, tile, nullptr, st, L));         // t
             float* pool = (L == 3) ? r->feats : nullptr;
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, tile, pool, st));                // out -> bb (+ avg-pool)
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, tile, pool, st, L));             // out -> bb (+ avg-pool)
             ci += 2;
             x = bb;
         }

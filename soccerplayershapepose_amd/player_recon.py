@@ -131,3 +131,35 @@ def unpack_record(rec):
     r.check(r.lib.spsp_unpack_record(r.ctx, rt.ptr(rec.contiguous()), B, rt.ptr(cam), rt.ptr(R), rt.ptr(betas), r.stream()),
             'spsp_unpack_record')
     return cam, R, betas
+
+
+class PlayerPipeline:
+    """Throughput mode of `reconstruct_players`: `depth` independent slots, each with its own HIP stream and its
+    own regressor / SMPL handles (a handle's workspace serves one call in flight).  Batches are issued round-robin,
+    so the latency-bound tail of batch i (IEF -> fit -> SMPL: a few wavefronts per player) runs on the GPU
+    underneath the MFMA-bound backbone of batch i+1.  Every batch still goes through the complete path; results
+    are returned with the event that marks their completion."""
+
+    def __init__(self, make_regressor, make_smpl, device, depth=2):
+        self.device = torch.device(device)
+        self.slots = []
+        for _ in range(depth):
+            st = torch.cuda.Stream(device=self.device)
+            self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
+                                              smpl=make_smpl().to(self.device), done=None))
+        self._next = 0
+
+    def submit(self, proxy_rep, joints2D, **kw):
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        slot.stream.wait_stream(torch.cuda.current_stream(self.device))     # inputs produced on the caller's stream
+        with torch.cuda.stream(slot.stream):
+            res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
+            res.done = torch.cuda.Event()
+            res.done.record(slot.stream)
+        res.stream = slot.stream
+        return res
+
+    def synchronize(self):
+        for s in self.slots:
+            s.stream.synchronize()
