@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per pipeline slot: HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues
+# round-robin, and two slots sharing a queue serialise their whole chains.  Must be set before HIP initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -43,7 +46,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='crops per GPU per step')
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--depth', type=int, default=2, help='pipeline slots (HIP streams); 1 = strictly serial steps')
+    ap.add_argument('--depth', type=int, default=4, help='pipeline slots (HIP streams); 1 = strictly serial steps')
     ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
     return ap.parse_args()
@@ -188,7 +191,7 @@ def main():
                                    f'fp32 accumulate) -> rot6d -> {FIT_ITERS}-iter {args.fit} Adam fit -> SMPL forward '
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
-                       'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,262,18] resident in HBM',
+                       'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth)},
             'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': (achieved / MFMA_BF16_PEAK_TFLOPS) if achieved else None,

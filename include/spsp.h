@@ -45,6 +45,8 @@ extern "C" {
 #define SPSP_PROXY_C        18
 #define SPSP_PROXY_WH       256
 #define SPSP_PROXY_PAD      3    /* zero border of the backbone-native input layout */
+#define SPSP_PROXY_NATIVE_H  262  /* 256 + 2*3 rows */
+#define SPSP_PROXY_NATIVE_W  264  /* 3 + 256 + 5 columns: row pitch 264*18*2 B = 9504 B is 16-byte aligned */
 
 typedef struct spsp_ctx       spsp_ctx;
 typedef struct spsp_regressor spsp_regressor;
@@ -95,7 +97,7 @@ int  spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max
 void spsp_regressor_free(spsp_regressor* r);
 
 #define SPSP_PROXY_NCHW_F32   0  /* [B,18,256,256] fp32 -- what the reference feeds (predict_3D.py:126) */
-#define SPSP_PROXY_NATIVE     1  /* [B,262,262,18] bf16 NHWC with a 3-px ZERO border (caller keeps it zero) */
+#define SPSP_PROXY_NATIVE     1  /* [B,262,264,18] bf16 NHWC, pixel (y,x) at [y+3][x+3], everything else ZERO (caller keeps it so) */
 
 /* Bytes of one crop in the native layout. */
 size_t spsp_proxy_native_bytes(void);

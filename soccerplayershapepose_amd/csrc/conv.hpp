@@ -38,4 +38,11 @@ int launch_conv(const ConvArgs& a, ConvTile tile, hipStream_t stream);
 enum RingTile { kRing128x128s3 = 0, kRing128x128s2, kRing128x64s3, kRing128x64s4, kRing64x128s3, kRing64x64s4, kRingNone };
 int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 
+// third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 px x 64 ch per workgroup
+bool conv_patch_supported(const ConvArgs& a);
+int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream);
+
+// conv1_patch.hip: the 7x7/2 stem with an LDS-resident 13-row input patch (4 output rows x 128 px x 64 ch per workgroup)
+int launch_conv1_patch(const ConvArgs& a, hipStream_t stream);
+
 }  // namespace spsp

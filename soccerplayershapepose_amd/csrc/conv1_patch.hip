@@ -1,0 +1,184 @@
+// conv1 (7x7 / stride 2 / pad 3, 18 -> 64 channels, 256x256 -> 128x128) with an LDS-RESIDENT INPUT PATCH.
+//
+// The first-generation conv1 (conv.hip, <128,64,128,8>) re-gathers every input row 3.5x (7 kernel rows / stride
+// 2) and every pixel 3.5x within a row: 940 MB of L2 -> LDS traffic per 32 crops for 79 MB of input; it is bound
+// by that path (262 TFLOP/s, 10 % of the MFMA peak).  Here a workgroup copies the 13 input rows that 4 output
+// rows need into LDS ONCE -- one contiguous 121 KB block of the native layout, so the LDS-DMA is a linear copy
+// -- and reads every MFMA pixel fragment straight from it:
+//   K-step = kernel row r (7 steps); the 7 taps x 18 channels of an output pixel are 126 contiguous bf16 of the
+//   input row (padded to 128 with two zero weights), starting 72*ox bytes into the row -> 8-byte aligned, so a
+//   16-byte fragment is two ds_read_b64.
+// Workgroup: 4 output rows x 128 pixels x 64 channels, 8 waves (two per SIMD), wave = (row, 64-pixel half),
+// wave tile 64 px x 64 ch on v_mfma_f32_16x16x32_bf16; the [64 x 128] weight slab of each kernel row streams
+// through a 2-stage LDS-DMA ring.  All fragment addresses are ONE per-lane base + immediates.
+#include <type_traits>
+
+#include "conv.hpp"
+
+namespace {
+using namespace spsp;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// 16-byte fragment from an 8-byte aligned address: two ds_read_b64 into the halves of one 128-bit register group
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_2xb64(uint32_t addr) {
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 8) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void dma16(const uint16_t* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int kRowB = 264 * 18 * 2;                 // 9504 bytes per padded input row
+constexpr int kPatchRows = 13;                      // 4 output rows: input rows 2*oy0 .. 2*oy0 + 12
+constexpr int kPatchPieces = (kPatchRows * kRowB + 1023) / 1024;   // 121 x 1 KiB
+constexpr int kPatchB = kPatchPieces * 1024;
+constexpr int kWStage = 64 * 256;                   // [64 n][128 k] bf16
+constexpr int kLds = kPatchB + 2 * kWStage;
+
+__global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    unsigned char* const ring = smem + kPatchB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = gridDim.x;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int b = tile >> 5, oy0 = (tile & 31) * 4;            // 32 row-quads per image
+
+    const uint16_t* const in_ptr = a.in;
+    const uint16_t* const w_ptr = a.w;
+    // ---- patch: linear copy of 13 contiguous rows ----
+    const uint16_t* psrc = in_ptr + (size_t)b * a.in_img + (size_t)(2 * oy0) * a.in_row + lane * 8;
+#pragma unroll
+    for (int i = 0; i < (kPatchPieces + 7) / 8; ++i) {
+        const int p = wave + 8 * i;
+        if (p < kPatchPieces) dma16(psrc + (size_t)p * 512, smem + p * 1024);
+    }
+    // ---- weight ring: stage r = [64 n][128 k]; piece = 4 rows x 256 B; lane l -> row l/16, physical chunk l%16 ----
+    const int drow = lane >> 4, dchunk = lane & 15;
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 4 + drow;
+        w_src[i] = w_ptr + (size_t)row * (7 * 128) + ((dchunk ^ (row & 15)) * 8);
+    }
+    auto issue_w = [&](int r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(w_src[i] + r * 128, ring + buf * kWStage + (wave * 2 + i) * 1024);
+    };
+    issue_w(0, 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int ry = wave >> 1, half = wave & 1;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    // weights: row i*16 + frow, chunk (ks*4 + fq) ^ frow  ->  base ^ (ks * 64)
+    const uint32_t w_lane = frow * 256 + ((fq ^ frow) * 16);
+    // pixels: input row 2*ry + r, byte 72*ox + 16*(ks*4 + fq), ox = half*64 + j*16 + frow
+    const uint32_t x_lane = smem_base + (2 * ry) * kRowB + (half * 64 + frow) * 72 + fq * 16;
+
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        wait_vmcnt<0>();                                   // patch (first step) + weight stage r
+        __builtin_amdgcn_s_barrier();
+        if (r + 1 < 7) issue_w(r + 1, (r + 1) & 1);
+        const uint32_t wbase = smem_base + kPatchB + (r & 1) * kWStage;
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {                   // two 32-deep k-substeps at a time
+            bf16x8 wf[2][4], xf[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ks = kp * 2 + kk;
+                const uint32_t wa = wbase + (w_lane ^ (ks * 64));
+                wf[kk][0] = lds_read_b128<0>(wa);
+                wf[kk][1] = lds_read_b128<4096>(wa);
+                wf[kk][2] = lds_read_b128<8192>(wa);
+                wf[kk][3] = lds_read_b128<12288>(wa);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                constexpr int J = 16 * 72;
+                const uint32_t xa = x_lane + r * kRowB + (kp * 2 + kk) * 64;
+                xf[kk][0] = lds_read_2xb64<0>(xa);
+                xf[kk][1] = lds_read_2xb64<J>(xa);
+                xf[kk][2] = lds_read_2xb64<2 * J>(xa);
+                xf[kk][3] = lds_read_2xb64<3 * J>(xa);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias + ReLU -> bf16 NHWC (1-px bordered output) ----
+    const int oy = oy0 + ry;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = half * 64 + j * 16 + frow;
+        const size_t obase = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)oy * a.out_row + (size_t)ox * a.out_pix;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = i * 16 + fq * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+            const f32x4 c = acc[i][j];
+            float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+    }
+}
+
+}  // namespace
+
+namespace spsp {
+
+int launch_conv1_patch(const ConvArgs& a, hipStream_t st) {
+    SPSP_REQUIRE(a.N == 64 && a.Ho == 128 && a.Wo == 128 && a.nsteps == 7 && a.stride == 2 && a.in_off == 0 &&
+                     a.in_pix == 18 && a.in_row == 264 * 18,
+                 "conv1_patch: geometry is fixed to the 7x7/2 stem on the [262,264,18] native layout");
+    static bool set = false;
+    if (!set) {
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_patch_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        set = true;
+    }
+    const int B = a.M / (128 * 128);
+    conv1_patch_kernel<<<dim3(B * 32), 512, kLds, st>>>(a);
+    SPSP_HIP_CHECK(hipGetLastError());
+    return SPSP_OK;
+}
+
+}  // namespace spsp

@@ -1,0 +1,353 @@
+// 3x3 / stride-1 convolution with an LDS-RESIDENT INPUT PATCH (third generation).
+//
+// Why: the implicit-GEMM kernels (conv.hip, conv_ring.hip) re-stage every input pixel once per filter tap, so a
+// 3x3 conv pulls 9x its input through the L2 -> LDS path, and that path (not HBM: the L2 hit rate is ~85 %, not
+// MFMA) is what they saturate at 32 crops.  Here a workgroup loads the (tile + halo) pixels of one 64-channel
+// chunk ONCE, keeps them in LDS, and feeds all 9 taps from there; only the [64 x 64] weight slab of each tap is
+// streamed (4-stage LDS-DMA ring).  Per workgroup: 256 output pixels x 64 output channels, 4 waves of 64 x 64,
+// v_mfma_f32_16x16x32_bf16, weights = A operand, pixels = B operand (lane = pixel -> 8-byte NHWC stores).
+//
+// L2 -> LDS bytes per MFMA cycle drop from 64-128 (implicit GEMM, 128x128..64x64 tiles) to ~16 (weights) + ~10
+// (patch), inside what one CU can pull from L2.
+//
+// Patch image: pixel-major [pixels][64 ch] bf16, 128 B per pixel, 16-byte chunk index XOR-swizzled by
+// f(q) = (q >> 1) & 7 of the patch pixel index q.  It is written by LDS-DMA (lane-linear: 8 pixels x 8 chunks per
+// wave-instruction, swizzle applied on the SOURCE chunk) and read with ds_read_b128; the swizzle of the shifted
+// pixel q + tap is recomputed per tap with 4 VALU ops that hide under the MFMAs.
+//
+// Tile geometries (W = feature-map width = height):
+//   W >= 16 : tile = 16 x 16 pixels of one image, patch 18 x 18; wave w owns rows 4w..4w+3, MFMA tile j = one row.
+//   W == 8  : tile = 4 whole 8 x 8 images, patch 4 x (10 x 10); wave w owns image w, MFMA tile j = rows 2j, 2j+1.
+//
+// Occupancy: ONE patch buffer + a 3-stage weight ring = 65-74 KB of LDS and <= 256 registers per lane, so two
+// workgroups share a CU (two waves per SIMD): while one wave runs its 32 MFMAs of a tap the other does its
+// LDS reads / DMA issue / epilogue.  (Measured on the first version, one wave per SIMD: 29 % MFMA-busy in layer4,
+// the rest was this wave's own VALU + LDS latency + barriers, serialised in front of its MFMAs.)  The patch of
+// the next 64-channel chunk can therefore only be fetched after the last tap of the current one; the partner
+// workgroup covers that bubble.
+#include <type_traits>
+
+#include "conv.hpp"
+
+namespace {
+using namespace spsp;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void dma16(const uint16_t* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int kWStage = 64 * 128;            // [64 n][64 k] bf16
+constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
+
+template <bool W8, int KS, int NS>
+struct Geo {
+    static constexpr int NW = 4 * KS;                             // waves per workgroup
+    static constexpr int PW = W8 ? 10 : 18;                       // patch row pitch in pixels
+    static constexpr int NPIX = W8 ? 400 : 324;                   // patch pixels
+    static constexpr int NDMA = (NPIX + 7) / 8;                   // 8 pixels per wave-instruction
+    static constexpr int PATCH = NDMA * 8 * kPixB;                // bytes (padded to whole DMA pieces)
+    static constexpr int DPW = (NDMA + NW - 1) / NW;              // patch DMA instructions per wave
+};
+
+// One workgroup: 256 pixels x 64 channels.  grid = (M/256) * (N/64) (XCD-contiguous order).
+template <bool W8, int KS, int NS>
+__global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs a) {
+    using G = Geo<W8, KS, NS>;
+    constexpr int PW = G::PW, kNS = NS, NW = G::NW;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    unsigned char* const ring = smem;                              // kNS x 8 KB weight stages
+    unsigned char* const patch0 = smem + kNS * kWStage;            // the patch
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3;                                  // which 64 pixels of the tile
+    const int kw = wave_id >> 2;                                   // KS == 2: which 32-deep half of every K-step
+    const int W = a.Wo;                                            // == Ho, == input W (stride 1)
+    const int mt = a.M / 256;
+    const int ntiles = mt * (a.N / 64);
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int m_tile = tile % mt, n_blk = (tile / mt) * 64;
+
+    // tile origin in the padded input (element offset of patch pixel (0,0), channel 0)
+    int img0, y0 = 0, x0 = 0;
+    if constexpr (W8) { img0 = m_tile * 4; }
+    else {
+        const int tpr = W / 16, tpi = tpr * tpr;                   // tiles per row / per image
+        img0 = m_tile / tpi;
+        const int t = m_tile - img0 * tpi;
+        y0 = (t / tpr) * 16; x0 = (t % tpr) * 16;
+    }
+    const int nchunks = a.chunks;                                  // Cin / 64
+    const uint16_t* const in_ptr = a.in;                           // scalar copies (keep the kernarg struct out of lambdas)
+    const uint16_t* const w_ptr = a.w;
+    const int Ktot = a.nsteps * 64;                                // 9 * Cin
+
+    // ---- patch LDS-DMA sources: lane l of piece p feeds patch pixel q = 8p + l/8, physical chunk l%8 ----
+    const int drow = lane >> 3, dchunk = lane & 7;
+    int p_src[G::DPW];                                             // element offsets into a.in (chunk 0)
+#pragma unroll
+    for (int i = 0; i < G::DPW; ++i) {
+        const int p = wave_id + NW * i;
+        int q = p * 8 + drow;
+        q = q < G::NPIX ? q : G::NPIX - 1;                         // tail lanes re-read the last pixel (harmless)
+        int off;
+        if constexpr (W8) {
+            const int im = q / 100, r = q - im * 100, py = r / 10, px = r - py * 10;
+            off = (img0 + im) * a.in_img + py * a.in_row + px * a.in_pix;
+        } else {
+            const int py = q / 18, px = q - py * 18;
+            off = img0 * a.in_img + (y0 + py) * a.in_row + (x0 + px) * a.in_pix;
+        }
+        p_src[i] = off + ((dchunk ^ ((q >> 1) & 7)) * 8);
+    }
+    auto issue_patch = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < G::DPW; ++i) {
+            const int p = wave_id + NW * i;
+            if (p < G::NDMA) dma16(in_ptr + p_src[i] + ch * 64, patch0 + p * 1024);
+        }
+    };
+    // ---- weight ring sources: stage = [64 n][64 k] of K-step g (tap-major, chunk-minor: g = tap*nchunks + ch) ----
+    constexpr int LPS = 2 / KS;                                    // weight pieces per wave per stage (8 per stage)
+    const uint16_t* w_src[LPS];
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int row = (wave_id * LPS + i) * 8 + drow;
+        w_src[i] = w_ptr + (size_t)(n_blk + row) * Ktot + ((dchunk ^ (row & 7)) * 8);
+    }
+    auto issue_w = [&](int g, int buf) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) dma16(w_src[i] + (size_t)g * 64, ring + buf * kWStage + (wave_id * LPS + i) * 1024);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    // weight fragment reads: row t*16 + frow, chunk (ks*4 + fq) ^ (frow & 7)
+    const uint32_t w_lane = frow * 128 + ((fq ^ (frow & 7)) * 16);
+    // patch pixel index of this lane for MFMA tile j = qb + j * QJ (tap adds r*PW + s)
+    int qb;
+    if constexpr (W8) qb = wave * 100 + (frow >> 3) * 10 + (frow & 7);
+    else qb = (wave * 4) * 18 + frow;
+    constexpr int QJ = W8 ? 20 : 18;
+
+    // LDS byte offsets of this lane's pixel fragments for every (tap, tile j), ks = 0 (ks = 1: chunk bit 2 flips).
+    // They do not depend on the chunk, so the 36 values live in registers for the whole kernel.
+    uint32_t xoff[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = qb + j * QJ + (tap / 3) * PW + (tap % 3);
+            xoff[tap][j] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ ((q >> 1) & 7)) * 16);
+        }
+
+    // K order inside the kernel: chunk-major, tap-minor (patch of chunk ch serves 9 consecutive steps); the weight
+    // matrix is stored tap-major/chunk-minor like the implicit-GEMM kernels, so step (ch, tap) reads K-step
+    // g = tap * nchunks + ch.
+    const int nsteps = 9 * nchunks;
+    auto gstep = [&](int s) { const int ch = s / 9, tap = s - ch * 9; return tap * nchunks + ch; };
+
+    issue_patch(0);
+    int issued = 0;
+    for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w(gstep(issued), issued);
+    int s = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const int ahead = issued - (s + 1);
+            if (ahead >= 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (tap == 0 && ch > 0) {
+                // every wave is past its last read of the previous chunk's patch: refill it, then wait for it
+                // (the weight stage issued below is younger, so vmcnt(LPS) covers the patch pieces)
+                issue_patch(ch);
+                if (issued < nsteps) { issue_w(gstep(issued), issued % kNS); ++issued; wait_vmcnt<LPS>(); }
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            } else if (issued < nsteps) { issue_w(gstep(issued), issued % kNS); ++issued; }
+
+            const uint32_t wbase = smem_base + (s % kNS) * kWStage;
+            if constexpr (KS == 1) {
+                bf16x8 wf[2][4], xf[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint32_t wa = wbase + (w_lane ^ (ks * 64));
+                    wf[ks][0] = lds_read_b128<0>(wa);
+                    wf[ks][1] = lds_read_b128<2048>(wa);
+                    wf[ks][2] = lds_read_b128<4096>(wa);
+                    wf[ks][3] = lds_read_b128<6144>(wa);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xf[ks][j] = lds_read_b128<0>(xoff[tap][j] ^ (ks * 64));
+                }
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);
+            } else {
+                // this wave's half of the step (k = 32*kw .. 32*kw+31); its SIMD partner wave does the other half
+                bf16x8 wf[4], xf[4];
+                const uint32_t wa = wbase + (w_lane ^ (kw * 64));
+                wf[0] = lds_read_b128<0>(wa);
+                wf[1] = lds_read_b128<2048>(wa);
+                wf[2] = lds_read_b128<4096>(wa);
+                wf[3] = lds_read_b128<6144>(wa);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] = lds_read_b128<0>(xoff[tap][j]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    if constexpr (KS == 2) {
+        // Combine the two K-halves: wave (kw, w) keeps channel tiles i = 2kw, 2kw+1 and hands the other two to its
+        // partner through LDS (ring + patch are dead by now; 8 waves x 8 KB).  Static register indices only.
+        __syncthreads();
+        float* xch = reinterpret_cast<float*>(smem);
+        auto put = [&](auto GIVE) {
+            constexpr int g = decltype(GIVE)::value;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(xch + ((size_t)(wave_id * 8 + ii * 4 + j) * 64 + lane) * 4) = acc[g + ii][j];
+        };
+        if (kw == 0) put(std::integral_constant<int, 2>{}); else put(std::integral_constant<int, 0>{});
+        __syncthreads();
+        const int partner = wave_id ^ 4;
+        auto get = [&](auto KEEP) {
+            constexpr int k = decltype(KEEP)::value;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[k + ii][j] += *reinterpret_cast<const f32x4*>(xch + ((size_t)(partner * 8 + ii * 4 + j) * 64 + lane) * 4);
+        };
+        if (kw == 0) get(std::integral_constant<int, 0>{}); else get(std::integral_constant<int, 2>{});
+    }
+
+    // ---- epilogue: lane = pixel (frow of tile j), 4 consecutive channels per accumulator; this wave finalises
+    //      channel tiles I0 .. I0 + 4/KS - 1 ----
+    auto epilogue = [&](auto I0c) {
+        constexpr int I0 = decltype(I0c)::value, NI = 4 / KS;
+        float psum[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) psum[i][0] = psum[i][1] = psum[i][2] = psum[i][3] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int b, y, x;
+            if constexpr (W8) { b = img0 + wave; y = 2 * j + (frow >> 3); x = frow & 7; }
+            else { b = img0; y = y0 + wave * 4 + j; x = x0 + frow; }
+            const size_t obase = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)y * a.out_row + (size_t)x * a.out_pix;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int n = n_blk + (I0 + i) * 16 + fq * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                const f32x4 c = acc[I0 + i][j];
+                float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
+                if (a.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
+                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                }
+                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
+            }
+        }
+        if constexpr (W8) {
+            if (a.pool_out) {
+                // fused global average pool (resnet.py:157): this wave holds all 64 pixels of image img0 + wave
+                const int b = img0 + wave;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = psum[i][r];
+                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                        if (frow == 0) a.pool_out[(size_t)b * a.N + n_blk + (I0 + i) * 16 + fq * 4 + r] = v * (1.0f / 64.0f);
+                    }
+            }
+        }
+    };
+    if constexpr (KS == 1) epilogue(std::integral_constant<int, 0>{});
+    else { if (kw == 0) epilogue(std::integral_constant<int, 0>{}); else epilogue(std::integral_constant<int, 2>{}); }
+}
+
+template <bool W8, int KS, int NS>
+int launch(const ConvArgs& a, hipStream_t st) {
+    using G = Geo<W8, KS, NS>;
+    constexpr size_t lds = (size_t)NS * kWStage + G::PATCH;
+    static_assert(lds >= 8 * 8192, "K-half exchange needs 64 KB");
+    static bool set = false;
+    if (!set) {
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    conv3x3_patch_kernel<W8, KS, NS><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(a);
+    SPSP_HIP_CHECK(hipGetLastError());
+    return SPSP_OK;
+}
+
+}  // namespace
+
+namespace spsp {
+
+bool conv_patch_supported(const ConvArgs& a) {
+    return a.stride == 1 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && a.in_off == 0 && a.M % 256 == 0 && a.N % 64 == 0 &&
+           a.Ho == a.Wo && (a.Wo == 8 || a.Wo % 16 == 0) && a.splitk <= 1;
+}
+
+int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream) {
+    SPSP_REQUIRE(conv_patch_supported(a), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
+    SPSP_REQUIRE(!a.pool_out || a.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
+    // variant 0: 4 waves, ring 3 (65-74 KB LDS: two workgroups per CU) -- many-workgroup layers
+    // variant 1: 8 waves (wave pairs split each K-step), ring 5 -- few-workgroup deep layers, one workgroup per CU
+    if (a.Wo == 8) return variant == 0 ? launch<true, 1, 3>(a, stream) : launch<true, 2, 5>(a, stream);
+    return variant == 0 ? launch<false, 1, 3>(a, stream) : launch<false, 2, 5>(a, stream);
+}
+
+}  // namespace spsp

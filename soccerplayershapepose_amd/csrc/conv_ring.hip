@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     constexpr int MT = BM / 32, NT = BN / 32;          // 16x16 tiles per wave (2x2 waves)
     static_assert(NS >= 2 && NS <= 4, "ring depth");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -1,8 +1,9 @@
-// GPU driver of the reprojection fit: one 64-lane wavefront per player, all iterations in one launch,
-// state in LDS (26 KB), Adam moments in registers.  The arithmetic lives in fit_core.hpp (shared with the
+// GPU driver of the reprojection fit: one 256-thread workgroup (4 wavefronts) per player, all iterations in one
+// launch, state in LDS (~29 KB), Adam moments in registers (one parameter per lane).  The arithmetic lives in fit_core.hpp (shared with the
 // host emulation used by the CPU tests).  Latency-bound by design (~27 single-wave barriers / iteration);
 // players are independent, so a batch fills one CU per player.
 #include <cmath>
+#include <cstdlib>
 
 #include "smpl.hpp"
 #include "fit_core.hpp"
@@ -10,16 +11,17 @@
 namespace {
 using namespace spsp;
 
-__global__ __launch_bounds__(64) void fit_kernel(FitParams P, const float* __restrict__ fitc,
+__global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const float* __restrict__ fitc,
                                                  const int* __restrict__ parents, const int* __restrict__ level_joints,
                                                  const int* __restrict__ level_start, const int* __restrict__ child_start,
                                                  const int* __restrict__ child_list, float* __restrict__ R,
                                                  float* __restrict__ betas, float* __restrict__ cam,
                                                  const float* __restrict__ joints2d, float* __restrict__ loss_hist,
-                                                 float* __restrict__ l2e_hist) {
+                                                 float* __restrict__ l2e_hist, unsigned long long* __restrict__ dbg) {
     __shared__ FitShared s;
     FitLane r;
     const int lane = threadIdx.x, b = blockIdx.x;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     float* Rb = R + (size_t)b * 216;
     float* bb = betas + (size_t)b * 10;
     float* cb = cam + (size_t)b * 3;
@@ -35,22 +37,49 @@ __global__ __launch_bounds__(64) void fit_kernel(FitParams P, const float* __res
         b2t *= P.beta2;
         const float step_size = (float)(P.lr / (1.0 - b1t));
         const float bc2_sqrt = (float)sqrt(1.0 - b2t);
+        // Phases that only involve lanes 0..63 run back to back inside wavefront 0 with NO workgroup barrier: a
+        // wave issues its LDS instructions in order, so a ds_write is visible to the following ds_read of any lane
+        // of the same wave.  That folds the 8 + 8 level-synchronous chain / reverse-sweep steps (<= 60 active lanes
+        // each) into two barrier-free runs: 9 barriers per iteration instead of 27.
+#define STAMP(i) if (dbg && it == 2 && b == 0 && lane == 0) dbg[i] = __builtin_amdgcn_s_memtime()
+        STAMP(0);
         fit_p1(s, lane);                       __syncthreads();
-        fit_p2(s, lane);                       __syncthreads();
-        for (int l = 1; l < L; ++l) { fit_chain_level(s, lane, l); __syncthreads(); }
+        STAMP(1);
+        if (wave0) {
+            fit_p2(s, lane);
+#pragma unroll
+            for (int l = 1; l < kMaxLevels; ++l)       // static l: the per-lane role tables stay in registers
+                if (l < L) fit_chain_level(s, r, lane, l);
+        }
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
         fit_p4(s, lane);                       __syncthreads();
-        fit_p5(s, lane);                       __syncthreads();
-        fit_p6(s, lane, P);                    __syncthreads();
+        STAMP(4);
+        if (wave0) { fit_p5(s, lane); fit_p6(s, r, lane, P); }
+        STAMP(5);
+        __syncthreads();
         fit_p7(s, lane);                       __syncthreads();
-        fit_p8(s, lane, P, it, lh, eh);        __syncthreads();
-        for (int l = L - 2; l >= 0; --l) { fit_reverse_level(s, lane, l); __syncthreads(); }
-        fit_p10(s, lane);                      __syncthreads();
+        STAMP(6);
+        if (wave0) {
+            fit_p8(s, lane, P, it, lh, eh);
+#pragma unroll
+            for (int l = kMaxLevels - 2; l >= 0; --l)
+                if (l <= L - 2) fit_reverse_level(s, r, lane, l);
+        }
+        STAMP(7);
+        __syncthreads();
+        fit_p10(s, r, lane);                   __syncthreads();
+        STAMP(8);
         fit_p11(s, lane);                      __syncthreads();
+        STAMP(9);
         fit_p12(s, r, lane, P, step_size, bc2_sqrt);
         __syncthreads();
+        STAMP(10);
     }
     const float* src = (P.select_mode == SPSP_FIT_SELECT_BEST_L2E) ? s.best : s.prm;
-    for (int p = lane; p < kNumPrm; p += 64) {
+    if (lane < kNumPrm) {
+        const int p = lane;
         const float v = src[p];
         if (p < kPrmR) cb[p] = v;
         else if (p < kPrmBeta) Rb[p - kPrmR] = v;
@@ -107,9 +136,20 @@ int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, 
     P.select_mode = cfg->select_mode;
     P.num_levels = s->num_levels;
     ProfScope ps(ctx, kKFit, as_stream(stream));
-    fit_kernel<<<B, 64, 0, as_stream(stream)>>>(P, s->fitc, s->parents, s->level_joints, s->d_level_start,
+    unsigned long long* dbg = nullptr;
+    if (getenv("SPSP_FIT_DEBUG")) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
+    fit_kernel<<<B, kFitLanes, 0, as_stream(stream)>>>(P, s->fitc, s->parents, s->level_joints, s->d_level_start,
                                                 s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist,
-                                                l2e_hist);
+                                                l2e_hist, dbg);
+    if (dbg) {
+        unsigned long long h[16];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+        const char* names[10] = {"p1+bar", "w0:p2+chain", "bar", "p4+bar", "w0:p5+p6", "bar+p7+bar", "w0:p8+reverse", "bar+p10+bar", "p11+bar", "p12+bar"};
+        for (int i = 0; i < 10; ++i) fprintf(stderr, "fit stamp %-14s %6llu cycles\n", names[i], h[i + 1] - h[i]);
+        fprintf(stderr, "fit iteration total %llu cycles\n", h[10] - h[0]);
+        (void)hipFree(dbg);
+    }
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

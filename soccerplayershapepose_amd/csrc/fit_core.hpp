@@ -9,8 +9,11 @@
 // A phase is a pure function of (lane, shared state): it reads LDS written by earlier phases and writes
 // disjoint LDS slots; a barrier separates consecutive phases.  No cross-lane register traffic is used
 // (reductions go through LDS partials), so the very same code runs
-//   * on the GPU   (fit.hip: 64 lanes = one wavefront, barrier = single-wave s_barrier), and
-//   * on the host  (tests/emul: `for lane in 0..63` per phase) -- a CPU check of the kernel's index math.
+//   * on the GPU   (fit.hip: kFitLanes = 256 lanes = 4 wavefronts per player, barrier = s_barrier), and
+//   * on the host  (tests/emul: `for lane in 0..255` per phase) -- a CPU check of the kernel's index math.
+// 256 lanes make every phase a SINGLE pass with <= ~25 FMAs per lane (one parameter per lane in the Adam
+// phase); the first version used one wavefront and spent its time in 2-4 pass loops (2470 VALU + 750 LDS
+// instructions per iteration, measured) -- the fit is latency-bound, so lanes are cheaper than passes.
 //
 // Reverse sweep (Appendix D).  With W_k = (Rw_k, tw_k) the world transform of joint k, p = parent(k):
 //   direct adjoints  a_k = dL/d tw_k = g_k + sum_v w_vk h_v,   B_k = dL/d Rw_k = sum_v w_vk h_v (vp_v - J_k)^T
@@ -32,6 +35,7 @@
 
 namespace spsp {
 
+constexpr int kFitLanes = 256;                // lanes (threads) cooperating on one player
 constexpr int kNumPrm = SPSP_RECORD_FLOATS;   // 229: [cam(3) | R(216) | betas(10)]
 constexpr int kPrmR = 3, kPrmBeta = 219;
 
@@ -57,8 +61,8 @@ struct FitShared {
     float W[288];
     float vp[16];
     float xf[16];
-    float part[64];
-    float part2[64];
+    float part[256];
+    float part2[256];
     float g[34];
     float ga[72];            // dL/d(tw_k) seeds of the chain joints that are fit targets (others stay 0; z stays 0)
     float h[16];             // dL/d(x_v) of the 5 face vertices (z stays 0)
@@ -66,15 +70,25 @@ struct FitShared {
     float rpart[17 * 5];     // per-fit-joint partials: loss, l2e, gs, gtx, gty
     float red[8];            // reduced: loss, l2e, gs, gtx, gty
     float adir[72], abar[72], Bbar[216];
-    float dvp[16], dJ[72], dJt[72];
+    float dvp[16], dJ[72];
+    float adj[96];           // [dvp(15) | dJ_total(72) | 0(9)]: what d(beta) contracts with fc[kFcC]
     float tgt_px[34];
     float best_l2e;
     int take_best;
     int parents[24], level_joints[24], level_start[26], child_start[25], child_list[24];
 };
 
-struct FitLane {             // per-lane registers that live across iterations
-    float m[4], v[4];
+constexpr int kMaxLevels = 12;   // tree depth limit (SMPL: 9 levels); checked at spsp_smpl_load
+
+// Per-lane registers that live across iterations: Adam moments of parameter `lane` and this lane's ROLE in the
+// level-synchronous phases (which joint, its parent, its children), looked up ONCE.  Reading the tree tables from
+// LDS inside the loop cost 4-5 dependent LDS round trips per level (measured: ~900 cycles per phase).
+struct FitLane {
+    float m, v;
+    signed char ck[kMaxLevels], cp[kMaxLevels];        // forward chain, level l: joint / parent handled (or -1)
+    signed char rp[kMaxLevels], rc[kMaxLevels][3];     // reverse sweep, level l: joint and its (<= 3) children (or -1)
+    signed char par216, par72;                         // parent of joint lane/9 (P10 rotation item) / lane/3 (dJ item)
+    signed char src17;                                 // P6: source joint of fit joint `lane`
 };
 
 SPSP_HD bool fit_trainable(uint32_t mask, int p) {
@@ -88,8 +102,9 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
                       const int* level_joints, const int* level_start, const int* child_start,
                       const int* child_list, const float* R, const float* betas, const float* cam,
                       const float* joints2d) {
-    for (int i = lane; i < kFcTotal; i += 64) s.fc[i] = fitc[i];
-    for (int p = lane; p < 232; p += 64) {
+    for (int i = lane; i < kFcTotal; i += kFitLanes) s.fc[i] = fitc[i];
+    if (lane < 232) {
+        const int p = lane;
         float v = 0.f;
         if (p < kPrmR) v = cam[p];
         else if (p < kPrmBeta) v = R[p - kPrmR];
@@ -110,78 +125,111 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
     {
         const int src_tab[17] = SPSP_FIT_SRC;
         if (lane < 17) s.fit_src[lane] = src_tab[lane];
-        for (int i = lane; i < 72; i += 64) s.ga[i] = 0.f;
+        if (lane < 72) s.ga[lane] = 0.f;
         if (lane < 16) s.h[lane] = 0.f;
+        if (lane < 96) s.adj[lane] = 0.f;
     }
-    for (int q = 0; q < 4; ++q) r.m[q] = r.v[q] = 0.f;
+    r.m = r.v = 0.f;
+    // roles (the tree tables are kernel arguments in global memory here; never touched again)
+    const int slot = lane / 12;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int l = 0; l < kMaxLevels; ++l) {
+        r.ck[l] = r.cp[l] = r.rp[l] = -1;
+        r.rc[l][0] = r.rc[l][1] = r.rc[l][2] = -1;
+        const int idx = level_start[l < 25 ? l : 25] + slot;
+        if (l < 25 && slot < 20 && idx < level_start[l + 1]) {
+            const int k = level_joints[idx];
+            r.ck[l] = (signed char)k;
+            r.cp[l] = (signed char)parents[k];
+            r.rp[l] = (signed char)k;
+            const int c0 = child_start[k], nc = child_start[k + 1] - c0;
+            if (nc > 0) r.rc[l][0] = (signed char)child_list[c0];
+            if (nc > 1) r.rc[l][1] = (signed char)child_list[c0 + 1];
+            if (nc > 2) r.rc[l][2] = (signed char)child_list[c0 + 2];
+        }
+    }
+    r.par216 = (signed char)(lane < 216 ? parents[lane / 9] : -1);
+    r.par72 = (signed char)(lane < 72 ? parents[lane / 3] : -1);
+    {
+        const int src_tab2[17] = SPSP_FIT_SRC;
+        r.src17 = (signed char)(lane < 17 ? src_tab2[lane] : 0);
+    }
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------
-// P1: J = Jbar + JS.beta (72 items); partial sums of the 5 posed face vertices over 4 chunks of the 207 pose
+// P1: J = Jbar + JS.beta (lanes 0..71); partial sums of the 5 posed face vertices over 16 chunks of 13 pose
 //     features (+ template + shape term in chunk 0).  lane = q*16 + c, c = v*3+i < 15.
+//     vp = vt5 + S5.beta + sum_j P5[j] (R[9+j] - delta_j): the delta part is folded into fc[kFcVt5] at load.
 SPSP_HD void fit_p1(FitShared& s, int lane) {
     const float* beta = s.prm + kPrmBeta;
-    for (int o = lane; o < 72; o += 64) {
-        float acc = s.fc[kFcJbar + o];
-        for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcJS + i * kJSPitch + o], beta[i], acc);
-        s.J[o] = acc;
+    if (lane < 72) {
+        float acc = s.fc[kFcJbar + lane];
+        for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcJS + i * kJSPitch + lane], beta[i], acc);
+        s.J[lane] = acc;
     }
     const int q = lane >> 4, c = lane & 15;
     float acc = 0.f;
     if (c < 15) {
-        if (q == 0) {
+        if (q == 15) {      // the shortest chunk (12 features) also carries the template + shape term
             acc = s.fc[kFcVt5 + c];
             for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcS5 + i * kF5Pitch + c], beta[i], acc);
         }
-        const int j0 = q * 52, j1 = (j0 + 52 < kNP) ? j0 + 52 : kNP;
-        for (int j = j0; j < j1; ++j) {
-            const int e = j % 9;
-            const float f = s.prm[kPrmR + 9 + j] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
-            acc = fmaf(s.fc[kFcP5 + j * kF5Pitch + c], f, acc);
-        }
+        // 16 x 13 = 208 rows: row 207 of P5 is a zero pad (prm[kPrmR + 216] = beta[0] is a finite dummy factor)
+        const float* P5 = s.fc + kFcP5 + (q * 13) * kF5Pitch + c;
+        const float* Rv = s.prm + kPrmR + 9 + q * 13;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int t = 0; t < 13; ++t) acc = fmaf(P5[t * kF5Pitch], Rv[t], acc);
     }
     s.part[lane] = acc;
 }
 
-// P2: finish vp; root transform W_0 = [G | J_0].
+// P2: finish vp (lanes 0..14: fixed-order sum of the 16 partials); root transform W_0 = [G | J_0] (lanes 16..27).
 SPSP_HD void fit_p2(FitShared& s, int lane) {
-    if (lane < 15) s.vp[lane] = (s.part[lane] + s.part[16 + lane]) + (s.part[32 + lane] + s.part[48 + lane]);
+    if (lane < 15) {
+        float acc = 0.f;
+        for (int q = 0; q < 16; ++q) acc += s.part[q * 16 + lane];
+        s.vp[lane] = acc;
+    }
     if (lane >= 16 && lane < 28) {
         const int e = lane - 16, i = e >> 2, c = e & 3;
         s.W[e] = (c < 3) ? s.prm[kPrmR + i * 3 + c] : s.J[i];
     }
 }
 
-// P3[l]: kinematic chain, level l >= 1: W_k = W_p * [R_k | J_k - J_p]; 5 joints x 12 elements per pass.
-SPSP_HD void fit_chain_level(FitShared& s, int lane, int l) {
-    const int slot = lane / 12, e = lane % 12, i = e >> 2, c = e & 3;
-    if (slot >= 5) return;
+// P3[l]: kinematic chain, level l >= 1: W_k = W_p * [R_k | J_k - J_p]; lane = (joint slot of the level, element).
+SPSP_HD void fit_chain_level(FitShared& s, const FitLane& r, int lane, int l) {
+    const int k = r.ck[l];
+    if (k < 0) return;
+    const int p = r.cp[l];
+    const int e = lane % 12, i = e >> 2, c = e & 3;
     const float* Rm = s.prm + kPrmR;
-    for (int idx = s.level_start[l] + slot; idx < s.level_start[l + 1]; idx += 5) {
-        const int k = s.level_joints[idx], p = s.parents[k];
-        const float* Wp = s.W + p * 12 + i * 4;
-        float acc;
-        if (c < 3) {
-            acc = Wp[0] * Rm[k * 9 + c];
-            acc = fmaf(Wp[1], Rm[k * 9 + 3 + c], acc);
-            acc = fmaf(Wp[2], Rm[k * 9 + 6 + c], acc);
-        } else {
-            acc = Wp[0] * (s.J[k * 3] - s.J[p * 3]);
-            acc = fmaf(Wp[1], s.J[k * 3 + 1] - s.J[p * 3 + 1], acc);
-            acc = fmaf(Wp[2], s.J[k * 3 + 2] - s.J[p * 3 + 2], acc);
-            acc += Wp[3];
-        }
-        s.W[k * 12 + e] = acc;
+    const float* Wp = s.W + p * 12 + i * 4;
+    float acc;
+    if (c < 3) {
+        acc = Wp[0] * Rm[k * 9 + c];
+        acc = fmaf(Wp[1], Rm[k * 9 + 3 + c], acc);
+        acc = fmaf(Wp[2], Rm[k * 9 + 6 + c], acc);
+    } else {
+        acc = Wp[0] * (s.J[k * 3] - s.J[p * 3]);
+        acc = fmaf(Wp[1], s.J[k * 3 + 1] - s.J[p * 3 + 1], acc);
+        acc = fmaf(Wp[2], s.J[k * 3 + 2] - s.J[p * 3 + 2], acc);
+        acc += Wp[3];
     }
+    s.W[k * 12 + e] = acc;
 }
 
-// P4: face vertices x_v = sum_k w_vk (Rw_k (vp_v - J_k) + tw_k); lane = q*16 + (v*3+i), q = 6-joint chunk.
+// P4: face vertices x_v = sum_k w_vk (Rw_k (vp_v - J_k) + tw_k); lane = q*16 + (v*3+i), q < 12 = pair of joints.
 SPSP_HD void fit_p4(FitShared& s, int lane) {
     const int q = lane >> 4, o = lane & 15;
+    if (q >= 12) return;
     float acc = 0.f;
     if (o < 15) {
         const int v = o / 3, i = o % 3;
-        for (int k = q * 6; k < q * 6 + 6; ++k) {
+        for (int k = q * 2; k < q * 2 + 2; ++k) {
             const float* w = s.W + k * 12 + i * 4;
             float t = fmaf(w[0], s.vp[v * 3] - s.J[k * 3],
                            fmaf(w[1], s.vp[v * 3 + 1] - s.J[k * 3 + 1],
@@ -193,15 +241,19 @@ SPSP_HD void fit_p4(FitShared& s, int lane) {
 }
 
 SPSP_HD void fit_p5(FitShared& s, int lane) {
-    if (lane < 15) s.xf[lane] = (s.part[lane] + s.part[16 + lane]) + (s.part[32 + lane] + s.part[48 + lane]);
+    if (lane < 15) {
+        float acc = 0.f;
+        for (int q = 0; q < 12; ++q) acc += s.part[q * 16 + lane];
+        s.xf[lane] = acc;
+    }
 }
 
 // P6: project the 17 fit joints, residuals, per-joint loss / l2e / camera-gradient partials, dL/dX.
 //     pixels = (s (X + t) + 1) * img_wh/2  (cam_utils.py:5-26, joints2d_utils.py:5-10);
 //     n = 2 px / loss_wh - 1 on both sides, L = mean(d^2) * w + lv  (multi_task_loss.py:97-113).
-SPSP_HD void fit_p6(FitShared& s, int lane, const FitParams& P) {
+SPSP_HD void fit_p6(FitShared& s, const FitLane& r, int lane, const FitParams& P) {
     if (lane >= 17) return;
-    const int src = s.fit_src[lane];
+    const int src = r.src17;
     float X[2];
     if (src < 24) { X[0] = s.W[src * 12 + 3]; X[1] = s.W[src * 12 + 7]; }
     else { X[0] = s.xf[(src - 24) * 3]; X[1] = s.xf[(src - 24) * 3 + 1]; }
@@ -233,53 +285,52 @@ SPSP_HD void fit_p6(FitShared& s, int lane, const FitParams& P) {
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
-SPSP_HD float fit_h(const FitShared& s, int v, int i) { return s.h[v * 3 + i]; }   // adjoint of face vertex v
-
-// P7: reductions of P6 (lanes 0..4); direct adjoints a_k, B_k; dvp partials; direct dJ.
+// P7: reductions of P6 (lanes 0..4); lanes 64..135: direct adjoints a_k, B_k and direct dJ for item (k, i);
+//     lanes 136..255: dvp partials over 3 joints each.
 SPSP_HD void fit_p7(FitShared& s, int lane) {
     if (lane < 5) {
         float acc = 0.f;
         for (int i = 0; i < 17; ++i) acc += s.rpart[i * 5 + lane];
         s.red[lane] = acc;
     }
-    for (int it = lane; it < 72; it += 64) {                 // item (k, i)
-        const int k = it / 3, i = it % 3;
+    if (lane >= 64 && lane < 136) {
+        const int it = lane - 64, k = it / 3, i = it % 3;
         float a = s.ga[it];
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, dj = 0.f;
         for (int v = 0; v < 5; ++v) {
-            const float wh = s.fc[kFcW5 + v * 24 + k] * fit_h(s, v, i);
+            const float w = s.fc[kFcW5 + v * 24 + k];
+            const float wh = w * s.h[v * 3 + i];
             a += wh;
             b0 = fmaf(wh, s.vp[v * 3] - s.J[k * 3], b0);
             b1 = fmaf(wh, s.vp[v * 3 + 1] - s.J[k * 3 + 1], b1);
             b2 = fmaf(wh, s.vp[v * 3 + 2] - s.J[k * 3 + 2], b2);
+            // direct dJ[k][l = i] = -sum_v w_vk sum_i' Rw_k[i'][l] h_v[i']   (h_v[2] == 0)
+            dj = fmaf(w, fmaf(s.W[k * 12 + i], s.h[v * 3], s.W[k * 12 + 4 + i] * s.h[v * 3 + 1]), dj);
         }
         s.adir[it] = a;
         s.abar[it] = a;
         s.Bbar[k * 9 + i * 3] = b0; s.Bbar[k * 9 + i * 3 + 1] = b1; s.Bbar[k * 9 + i * 3 + 2] = b2;
+        s.dJ[it] = -dj;
     }
-    {   // dvp[v][l] partial over 6 joints: sum_k w_vk sum_i Rw_k[i][l] h_v[i]
-        const int q = lane >> 4, o = lane & 15;
+    if (lane >= 136) {   // dvp[v][l] partial over joints 3q..3q+2: sum_k w_vk sum_i Rw_k[i][l] h_v[i]
+        const int idx = lane - 136, q = idx / 15, o = idx % 15;
+        const int v = o / 3, l = o % 3;
+        const float h0 = s.h[v * 3], h1 = s.h[v * 3 + 1];
         float acc = 0.f;
-        if (o < 15) {
-            const int v = o / 3, l = o % 3;
-            const float h0 = fit_h(s, v, 0), h1 = fit_h(s, v, 1);
-            for (int k = q * 6; k < q * 6 + 6; ++k)
-                acc = fmaf(s.fc[kFcW5 + v * 24 + k], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
-        }
-        s.part2[lane] = acc;
-    }
-    for (int it = lane; it < 72; it += 64) {                 // direct dJ[k][l] = -sum_v w_vk sum_i Rw_k[i][l] h_v[i]
-        const int k = it / 3, l = it % 3;
-        float acc = 0.f;
-        for (int v = 0; v < 5; ++v)
-            acc = fmaf(s.fc[kFcW5 + v * 24 + k], fmaf(s.W[k * 12 + l], fit_h(s, v, 0), s.W[k * 12 + 4 + l] * fit_h(s, v, 1)), acc);
-        s.dJ[it] = -acc;
+        for (int k = q * 3; k < q * 3 + 3; ++k)
+            acc = fmaf(s.fc[kFcW5 + v * 24 + k], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
+        s.part2[q * 16 + o] = acc;
     }
 }
 
 // P8: finish dvp; lane 63 turns the reductions into loss / l2e, history and the best-iterate decision.
 SPSP_HD void fit_p8(FitShared& s, int lane, const FitParams& P, int it, float* loss_hist, float* l2e_hist) {
-    if (lane < 15) s.dvp[lane] = (s.part2[lane] + s.part2[16 + lane]) + (s.part2[32 + lane] + s.part2[48 + lane]);
+    if (lane < 15) {
+        float acc = 0.f;
+        for (int q = 0; q < 8; ++q) acc += s.part2[q * 16 + lane];
+        s.dvp[lane] = acc;
+        s.adj[lane] = acc;
+    }
     if (lane == 63) {
         const float loss = (s.red[0] / 34.0f) * P.weight + P.log_var;
         const float l2e = s.red[1] / 17.0f;
@@ -292,94 +343,110 @@ SPSP_HD void fit_p8(FitShared& s, int lane, const FitParams& P, int it, float* l
 }
 
 // P9[l]: reverse sweep -- every joint p of level l gathers from its children (level l+1, already final).
-SPSP_HD void fit_reverse_level(FitShared& s, int lane, int l) {
-    const int slot = lane / 12, e = lane % 12;
-    if (slot >= 5) return;
+SPSP_HD void fit_reverse_level(FitShared& s, const FitLane& r, int lane, int l) {
+    const int p = r.rp[l];
+    if (p < 0) return;
+    const int e = lane % 12;
     const float* Rm = s.prm + kPrmR;
-    for (int idx = s.level_start[l] + slot; idx < s.level_start[l + 1]; idx += 5) {
-        const int p = s.level_joints[idx];
-        if (e < 3) {
-            float acc = s.abar[p * 3 + e];
-            for (int ci = s.child_start[p]; ci < s.child_start[p + 1]; ++ci) acc += s.abar[s.child_list[ci] * 3 + e];
-            s.abar[p * 3 + e] = acc;
-        } else {
-            const int i = (e - 3) / 3, c = (e - 3) % 3;
-            float acc = s.Bbar[p * 9 + i * 3 + c];
-            for (int ci = s.child_start[p]; ci < s.child_start[p + 1]; ++ci) {
-                const int ch = s.child_list[ci];
-                acc = fmaf(s.abar[ch * 3 + i], s.J[ch * 3 + c] - s.J[p * 3 + c], acc);
-                const float* Bc = s.Bbar + ch * 9 + i * 3;
-                const float* Rc = Rm + ch * 9 + c * 3;     // row c of R_child:  (Bbar_c R_c^T)[i][c] = sum_m Bbar_c[i][m] R_c[c][m]
-                acc = fmaf(Bc[0], Rc[0], fmaf(Bc[1], Rc[1], fmaf(Bc[2], Rc[2], acc)));
-            }
-            s.Bbar[p * 9 + i * 3 + c] = acc;
+    if (e < 3) {
+        float acc = s.abar[p * 3 + e];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int n = 0; n < 3; ++n) {
+            const int ch = r.rc[l][n];
+            if (ch >= 0) acc += s.abar[ch * 3 + e];
         }
+        s.abar[p * 3 + e] = acc;
+    } else {
+        const int i = (e - 3) / 3, c = (e - 3) % 3;
+        float acc = s.Bbar[p * 9 + i * 3 + c];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int n = 0; n < 3; ++n) {
+            const int ch = r.rc[l][n];
+            if (ch < 0) continue;
+            acc = fmaf(s.abar[ch * 3 + i], s.J[ch * 3 + c] - s.J[p * 3 + c], acc);
+            const float* Bc = s.Bbar + ch * 9 + i * 3;
+            const float* Rc = Rm + ch * 9 + c * 3;     // row c of R_child:  (Bbar_c R_c^T)[i][c] = sum_m Bbar_c[i][m] R_c[c][m]
+            acc = fmaf(Bc[0], Rc[0], fmaf(Bc[1], Rc[1], fmaf(Bc[2], Rc[2], acc)));
+        }
+        s.Bbar[p * 9 + i * 3 + c] = acc;
     }
 }
 
-// P10: rotation gradients (incl. the pose-blend-shape path through the face vertices) and total dJ.
-SPSP_HD void fit_p10(FitShared& s, int lane) {
-    for (int it = lane; it < 216; it += 64) {                // item (k, l, c): dR_k[l][c]
-        const int k = it / 9, e = it % 9, l = e / 3, c = e % 3;
+// P10: rotation gradients incl. the pose-blend-shape path through the face vertices (lanes 0..215) and the
+//      total dJ (lanes 0..71, after their rotation item).
+SPSP_HD void fit_p10(FitShared& s, const FitLane& r, int lane) {
+    if (lane < 216) {                                        // item (k, l, c): dR_k[l][c]
+        const int k = lane / 9, e = lane % 9, l = e / 3, c = e % 3;
         float acc;
         if (k == 0) acc = s.Bbar[e];
         else {
-            const float* Wp = s.W + s.parents[k] * 12;
+            const float* Wp = s.W + r.par216 * 12;
             acc = Wp[l] * s.Bbar[k * 9 + c];
             acc = fmaf(Wp[4 + l], s.Bbar[k * 9 + 3 + c], acc);
             acc = fmaf(Wp[8 + l], s.Bbar[k * 9 + 6 + c], acc);
             const float* P5 = s.fc + kFcP5 + ((k - 1) * 9 + e) * kF5Pitch;
             for (int o = 0; o < 15; ++o) acc = fmaf(P5[o], s.dvp[o], acc);
         }
-        s.grad[kPrmR + it] = acc;
+        s.grad[kPrmR + lane] = acc;
     }
-    for (int it = lane; it < 72; it += 64) {                 // dJ_total[k][l]
-        const int k = it / 3, l = it % 3;
-        float acc = s.dJ[it];
+    if (lane < 72) {                                         // dJ_total[k][l]
+        const int k = lane / 3, l = lane % 3;
+        float acc = s.dJ[lane];
         if (k == 0) acc += s.abar[l];
         else {
-            const float* Wp = s.W + s.parents[k] * 12;
+            const float* Wp = s.W + r.par72 * 12;
             acc = fmaf(Wp[l], s.abar[k * 3], fmaf(Wp[4 + l], s.abar[k * 3 + 1], fmaf(Wp[8 + l], s.abar[k * 3 + 2], acc)));
         }
         const float* Wk = s.W + k * 12;
         const float c0 = s.abar[k * 3] - s.adir[k * 3], c1 = s.abar[k * 3 + 1] - s.adir[k * 3 + 1],
                     c2 = s.abar[k * 3 + 2] - s.adir[k * 3 + 2];
         acc -= fmaf(Wk[l], c0, fmaf(Wk[4 + l], c1, Wk[8 + l] * c2));
-        s.dJt[it] = acc;
+        s.adj[15 + lane] = acc;
     }
 }
 
-// P11: d beta partials over 4 chunks of the concatenated adjoint [dvp(15) | dJt(72)]; lane = q*16 + i.
+// P11: d beta partials over 16 chunks of 6 of the adjoint vector adj = [dvp(15) | dJ_total(72) | 0(9)];
+//      lane = q*16 + i, i < 10.
 SPSP_HD void fit_p11(FitShared& s, int lane) {
     const int q = lane >> 4, i = lane & 15;
     float acc = 0.f;
     if (i < 10) {
-        for (int o = q * 22; o < q * 22 + 22 && o < 87; ++o)
-            acc = (o < 15) ? fmaf(s.fc[kFcS5 + i * kF5Pitch + o], s.dvp[o], acc)
-                           : fmaf(s.fc[kFcJS + i * kJSPitch + (o - 15)], s.dJt[o - 15], acc);
+        const float* C = s.fc + kFcC + i * kCPitch + q * 6;
+        const float* A = s.adj + q * 6;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int t = 0; t < 6; ++t) acc = fmaf(C[t], A[t], acc);
     }
     s.part[lane] = acc;
 }
 
-// P12: best-iterate snapshot (pre-step parameters) and the torch.optim.Adam step (single-tensor path):
+// P12: best-iterate snapshot (pre-step parameters) and the torch.optim.Adam step (single-tensor path), one
+//   parameter per lane:
 //   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(1-b2^t) + eps; p += (-lr/(1-b1^t) * m) / denom
 SPSP_HD void fit_p12(FitShared& s, FitLane& r, int lane, const FitParams& P, float step_size, float bc2_sqrt) {
+    const int p = lane;
+    if (p >= kNumPrm) return;
     const float w1 = (float)(1.0 - P.beta1), b2 = (float)P.beta2, w2 = (float)(1.0 - P.beta2), eps = (float)P.eps;
-    for (int q = 0; q < 4; ++q) {
-        const int p = lane + 64 * q;
-        if (p >= kNumPrm) break;
-        const float cur = s.prm[p];
-        if (s.take_best) s.best[p] = cur;
-        if (!fit_trainable(P.param_mask, p)) continue;
-        float g;
-        if (p < kPrmR) g = s.red[2 + p];
-        else if (p < kPrmBeta) g = s.grad[p];
-        else { const int i = p - kPrmBeta; g = (s.part[i] + s.part[16 + i]) + (s.part[32 + i] + s.part[48 + i]); }
-        r.m[q] = r.m[q] + w1 * (g - r.m[q]);
-        r.v[q] = r.v[q] * b2 + (w2 * g) * g;
-        const float denom = sqrtf(r.v[q]) / bc2_sqrt + eps;
-        s.prm[p] = cur + ((-step_size) * r.m[q]) / denom;
+    const float cur = s.prm[p];
+    if (s.take_best) s.best[p] = cur;
+    if (!fit_trainable(P.param_mask, p)) return;
+    float g;
+    if (p < kPrmR) g = s.red[2 + p];
+    else if (p < kPrmBeta) g = s.grad[p];
+    else {
+        const int i = p - kPrmBeta;
+        g = 0.f;
+        for (int q = 0; q < 16; ++q) g += s.part[q * 16 + i];
     }
+    r.m = r.m + w1 * (g - r.m);
+    r.v = r.v * b2 + (w2 * g) * g;
+    const float denom = sqrtf(r.v) / bc2_sqrt + eps;
+    s.prm[p] = cur + ((-step_size) * r.m) / denom;
 }
 
 }  // namespace spsp

@@ -11,8 +11,8 @@ namespace {
 using namespace spsp;
 
 constexpr int kWH = SPSP_PROXY_WH, kCin = SPSP_PROXY_C, kPad = SPSP_PROXY_PAD;
-constexpr int kWHp = kWH + 2 * kPad;                       // 262
-constexpr size_t kNativeElems = (size_t)kWHp * kWHp * kCin;
+constexpr int kWHp = SPSP_PROXY_NATIVE_H, kWWp = SPSP_PROXY_NATIVE_W;   // 262 rows x 264 columns
+constexpr size_t kNativeElems = (size_t)kWHp * kWWp * kCin;
 constexpr int kFeat = 512, kNPar = 157, kHid = 512;
 
 struct ConvDesc { const char* name; const char* bn; int cout, cin, k, stride; };
@@ -40,13 +40,13 @@ const ConvDesc kConvs[SPSP_NUM_CONVS] = {
 };
 
 // ---- layout kernels -------------------------------------------------------------------------------------
-// NCHW fp32 [B,18,256,256] -> native [B,262,262,18] bf16 (interior + zero border).
+// NCHW fp32 [B,18,256,256] -> native [B,262,264,18] bf16 (interior + zero border).
 __global__ void proxy_pack_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst) {
     const int xp = blockIdx.x * blockDim.x + threadIdx.x, yp = blockIdx.y, b = blockIdx.z;
-    if (xp >= kWHp) return;
+    if (xp >= kWWp) return;
     const int x = xp - kPad, y = yp - kPad;
     const bool inside = x >= 0 && x < kWH && y >= 0 && y < kWH;
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst + ((size_t)b * kWHp * kWHp + (size_t)yp * kWHp + xp) * kCin);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst + ((size_t)b * kWHp * kWWp + (size_t)yp * kWWp + xp) * kCin);
     const float* s = src + (size_t)b * kCin * kWH * kWH + (size_t)y * kWH + x;
 #pragma unroll
     for (int c = 0; c < kCin; c += 2) {
@@ -203,6 +203,9 @@ struct spsp_regressor {
     // per residual stage: ring tile (kRingNone = first-generation kernel) and split-K factor
     RingTile ring[4];
     int splitk[4];
+    bool use_patch;        // 3x3 stride-1 convs through conv_patch.hip
+    bool conv1_patch;      // stem through conv1_patch.hip
+    int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs)
 };
 
 namespace {
@@ -219,6 +222,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     a.in = in; a.w = r->w[ci]; a.bias = r->bias[ci]; a.res = res; a.out = out; a.pool_out = pool_out;
     const int Wi = Si + 2 * bi;
     a.in_pix = d.cin; a.in_row = Wi * d.cin; a.in_img = Wi * Wi * d.cin;
+    if (ci == 0) { a.in_row = kWWp * d.cin; a.in_img = kWHp * kWWp * d.cin; }     // native input: 262 rows x 264 columns
     const int conv_pad = d.k / 2;
     a.in_off = (bi - conv_pad) * (a.in_row + a.in_pix);
     const int So = Si / d.stride;
@@ -230,6 +234,11 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
     a.relu = relu;
     a.splitk = 1;
+    if (L >= 0 && r->use_patch && conv_patch_supported(a)) {
+        const int kid3 = L == 0 ? kKConvL1 : L == 1 ? kKConvL2 : L == 2 ? kKConvL3 : kKConvL4;
+        ProfScope ps(ctx, kid3, st);
+        return launch_conv_patch(a, r->patch_variant[L], st);
+    }
     if (L >= 0 && r->ring[L] != kRingNone) {
         const RingTile rt = r->ring[L];
         const int bm = (rt == kRing64x128s3 || rt == kRing64x64s4) ? 64 : 128;
@@ -243,6 +252,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
             ProfScope ps(ctx, kid2, st);
             return launch_conv_ring(a, rt, st);
         }
+    }
+    if (ci == 0 && r->conv1_patch) {
+        ProfScope ps(ctx, kKConv1, st);
+        return launch_conv1_patch(a, st);
     }
     const int kid = tile == kTileConv1 ? kKConv1 : tile == kTile128x64 ? kKConvL1 : tile == kTile128x128 ? kKConvL2
                   : tile == kTile64x128 ? kKConvL3 : kKConvL4;
@@ -317,6 +330,14 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};   // measured best at 32 crops
         const int def_s[4] = {1, 1, 1, 1};
         for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->splitk[L] = def_s[L]; }
+        r->use_patch = true;
+        if (const char* pe = getenv("SPSP_CONV_PATCH")) r->use_patch = atoi(pe) != 0;
+        r->conv1_patch = true;
+        if (const char* pe = getenv("SPSP_CONV1_PATCH")) r->conv1_patch = atoi(pe) != 0;
+        const int def_v[4] = {0, 1, 1, 1};
+        for (int L = 0; L < 4; ++L) r->patch_variant[L] = def_v[L];
+        if (const char* pv = getenv("SPSP_PATCH_VARIANT"))       // e.g. "0111"
+            for (int L = 0; L < 4 && pv[L]; ++L) r->patch_variant[L] = pv[L] == '1';
         if (const char* env = getenv("SPSP_CONV_PLAN")) {
             std::string e(env);
             size_t pos = 0;
@@ -348,7 +369,7 @@ void spsp_regressor_free(spsp_regressor* r) { delete r; }
 int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_out, void* stream) {
     SPSP_REQUIRE(ctx && proxy_nchw && native_out && B >= 0, "spsp_proxy_pack: bad arguments");
     if (B == 0) return SPSP_OK;
-    dim3 grid((kWHp + 63) / 64, kWHp, B);
+    dim3 grid((kWWp + 63) / 64, kWHp, B);
     ProfScope ps(ctx, kKProxyPack, as_stream(stream));
     proxy_pack_kernel<<<grid, 64, 0, as_stream(stream)>>>(proxy_nchw, static_cast<uint16_t*>(native_out));
     SPSP_HIP_CHECK(hipGetLastError());

@@ -21,8 +21,11 @@ constexpr int kFcJbar = 0;                                // [24][3]
 constexpr int kFcJS = kFcJbar + 72;                       // [10][73]   JS[i][k*3+c]
 constexpr int kFcVt5 = kFcJS + 10 * kJSPitch;             // [16]       template coords of the 5 face verts (15 used)
 constexpr int kFcS5 = kFcVt5 + 16;                        // [10][17]   shapedirs rows of the 5 face verts
-constexpr int kFcP5 = kFcS5 + 10 * kF5Pitch;              // [207][17]  posedirs columns of the 5 face verts
-constexpr int kFcW5 = kFcP5 + 207 * kF5Pitch;             // [5][24]    lbs weights of the 5 face verts
-constexpr int kFcTotal = kFcW5 + 120;                     // 4627 floats = 18.5 KB
+constexpr int kFcP5 = kFcS5 + 10 * kF5Pitch;              // [208][17]  posedirs columns of the 5 face verts (+1 zero row)
+constexpr int kFcW5 = kFcP5 + 208 * kF5Pitch;             // [5][24]    lbs weights of the 5 face verts
+constexpr int kCPitch = 97;
+constexpr int kFcC = kFcW5 + 120;                         // [10][97]   d(beta) coefficients over the 96-long adjoint
+                                                          //            [dvp(15) | dJ(72) | 0(9)]: S5 | JS | 0
+constexpr int kFcTotal = kFcC + 10 * kCPitch;             // 5614 floats = 22.5 KB
 
 }  // namespace spsp

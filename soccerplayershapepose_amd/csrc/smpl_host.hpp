@@ -88,6 +88,12 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
             maxd = std::max(maxd, depth[k]);
         }
         h.num_levels = maxd + 1;
+        if (h.num_levels > 12) return "kinematic tree deeper than 12 levels (fit kernel limit; SMPL has 9)";
+        for (int k = 0; k < kNJ; ++k) {
+            int nc = 0;
+            for (int c = 1; c < kNJ; ++c) nc += a.parents[c] == k;
+            if (nc > 3) return "a joint with more than 3 children (fit kernel limit; SMPL has at most 3)";
+        }
         h.level_joints.clear();
         for (int l = 0; l <= maxd; ++l) {
             h.level_start[l] = (int)h.level_joints.size();
@@ -95,6 +101,8 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
                 if (depth[k] == l) h.level_joints.push_back(k);
         }
         for (int l = maxd + 1; l < 26; ++l) h.level_start[l] = (int)h.level_joints.size();
+        for (int l = 0; l <= maxd; ++l)
+            if (h.level_start[l + 1] - h.level_start[l] > 5) return "more than 5 joints on one tree level (fit kernel limit; SMPL has at most 5)";
         int n = 0;
         std::memset(h.child_list, 0, sizeof h.child_list);
         for (int k = 0; k < kNJ; ++k) {
@@ -118,6 +126,18 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
             for (int j = 0; j < kNP; ++j) h.fitc[kFcP5 + j * kF5Pitch + f * 3 + c] = a.posedirs[(size_t)j * kV3 + 3 * v + c];
         }
         for (int k = 0; k < kNJ; ++k) h.fitc[kFcW5 + f * 24 + k] = a.lbs_weights[(size_t)v * kNJ + k];
+    }
+    for (int i = 0; i < kNB; ++i) {
+        for (int o = 0; o < 15; ++o) h.fitc[kFcC + i * kCPitch + o] = h.fitc[kFcS5 + i * kF5Pitch + o];
+        for (int o = 0; o < 72; ++o) h.fitc[kFcC + i * kCPitch + 15 + o] = h.fitc[kFcJS + i * kJSPitch + o];
+    }
+    // The pose feature is R[1:] - I; the kernel contracts posedirs with R directly, so the identity part
+    // (-sum over the diagonal entries j % 9 in {0,4,8}) is folded into the template term once, in float64.
+    for (int c = 0; c < 15; ++c) {
+        double acc = h.fitc[kFcVt5 + c];
+        for (int j = 0; j < kNP; ++j)
+            if (j % 9 == 0 || j % 9 == 4 || j % 9 == 8) acc -= (double)h.fitc[kFcP5 + j * kF5Pitch + c];
+        h.fitc[kFcVt5 + c] = (float)acc;
     }
     return "";
 }

@@ -121,20 +121,20 @@ class SingleInputRegressor:
 
     # -- forward ------------------------------------------------------------------------------------
     def pack(self, proxy_nchw):
-        """NCHW fp32 [B,18,256,256] -> backbone-native [B,262,262,18] bf16 (zero border) device tensor."""
+        """NCHW fp32 [B,18,256,256] -> backbone-native [B,262,264,18] bf16 (zero border) device tensor."""
         x = rt.dev_f32(proxy_nchw)
         r = rt.get(x.device)
         if x.dim() != 4 or tuple(x.shape[1:]) != (18, 256, 256):
             raise ValueError(f'proxy representation must be [B,18,256,256], got {tuple(x.shape)}')
-        out = torch.empty((x.shape[0], 262, 262, 18), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((x.shape[0], 262, 264, 18), dtype=torch.bfloat16, device=x.device)
         r.check(r.lib.spsp_proxy_pack(r.ctx, rt.ptr(x), x.shape[0], rt.ptr(out), r.stream()), 'spsp_proxy_pack')
         return out
 
     def forward(self, input, return_feats=False):
         native = isinstance(input, torch.Tensor) and input.dtype == torch.bfloat16
         if native:
-            if input.dim() != 4 or tuple(input.shape[1:]) != (262, 262, 18) or not input.is_cuda:
-                raise ValueError(f'native proxy must be a CUDA bf16 [B,262,262,18] tensor, got {tuple(input.shape)}')
+            if input.dim() != 4 or tuple(input.shape[1:]) != (262, 264, 18) or not input.is_cuda:
+                raise ValueError(f'native proxy must be a CUDA bf16 [B,262,264,18] tensor, got {tuple(input.shape)}')
             x = input.contiguous()
         else:
             x = rt.dev_f32(input)

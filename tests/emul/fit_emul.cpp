@@ -12,7 +12,7 @@
 
 using namespace spsp;
 
-#define ALL_LANES(stmt) for (int lane = 0; lane < 64; ++lane) { stmt; }
+#define ALL_LANES(stmt) for (int lane = 0; lane < kFitLanes; ++lane) { stmt; }
 
 extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
                            double beta1, double beta2, double eps, unsigned param_mask, float img_wh, float loss_wh,
@@ -33,7 +33,7 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
     std::vector<FitShared> sv(1);
     FitShared& s = sv[0];
     for (int b = 0; b < B; ++b) {
-        FitLane r[64];
+        FitLane r[kFitLanes];
         float* Rb = R + (size_t)b * 216; float* bb = betas + (size_t)b * 10; float* cb = cam + (size_t)b * 3;
         ALL_LANES(fit_init(s, r[lane], lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb,
                            cb, joints2d + (size_t)b * 34));
@@ -47,21 +47,21 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
             const float bc2_sqrt = (float)std::sqrt(1.0 - b2t);
             ALL_LANES(fit_p1(s, lane));
             ALL_LANES(fit_p2(s, lane));
-            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, lane, l)); }
+            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], lane, l)); }
             ALL_LANES(fit_p4(s, lane));
             ALL_LANES(fit_p5(s, lane));
-            ALL_LANES(fit_p6(s, lane, P));
+            ALL_LANES(fit_p6(s, r[lane], lane, P));
             ALL_LANES(fit_p7(s, lane));
             ALL_LANES(fit_p8(s, lane, P, it, lh, eh));
-            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, lane, l)); }
-            ALL_LANES(fit_p10(s, lane));
+            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], lane, l)); }
+            ALL_LANES(fit_p10(s, r[lane], lane));
             ALL_LANES(fit_p11(s, lane));
             if (it == 0 && grad_first) {      // gradient of the first iteration, record order [cam|R|betas]
                 float* g = grad_first + (size_t)b * kNumPrm;
                 for (int p = 0; p < kNumPrm; ++p)
                     g[p] = p < kPrmR ? s.red[2 + p]
                          : p < kPrmBeta ? s.grad[p]
-                         : (s.part[p - kPrmBeta] + s.part[16 + p - kPrmBeta]) + (s.part[32 + p - kPrmBeta] + s.part[48 + p - kPrmBeta]);
+                         : [&] { float t = 0.f; for (int q = 0; q < 16; ++q) t += s.part[q * 16 + (p - kPrmBeta)]; return t; }();
             }
             ALL_LANES(fit_p12(s, r[lane], lane, P, step_size, bc2_sqrt));
         }

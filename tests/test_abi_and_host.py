@@ -52,7 +52,7 @@ def test_profile_kernel_names_and_native_layout_size():
     n = lib.spsp_profile_num_kernels()
     names = [lib.spsp_profile_kernel_name(i).decode() for i in range(n)]
     assert 'fit_kernel' in names and sum(k.startswith('conv_igemm_kernel') for k in names) == 5
-    assert lib.spsp_proxy_native_bytes() == 262 * 262 * 18 * 2
+    assert lib.spsp_proxy_native_bytes() == 262 * 264 * 18 * 2
 
 
 def test_smpl_array_validation_on_host(smpl_model_np):

@@ -277,13 +277,13 @@ def test_regressor_native_input_batch_invariance_and_limits(regressor_gpu, dev):
     xt = torch.from_numpy(x).to(dev)
     cam, pose, shape = regressor_gpu(xt)
     native = regressor_gpu.pack(xt)
-    assert native.shape == (32, 262, 262, 18) and native.dtype == torch.bfloat16
-    assert native[:, :3].abs().max().item() == 0 and native[:, :, -3:].abs().max().item() == 0
+    assert native.shape == (32, 262, 264, 18) and native.dtype == torch.bfloat16
+    assert native[:, :3].abs().max().item() == 0 and native[:, :, -5:].abs().max().item() == 0 and native[:, -3:].abs().max().item() == 0 and native[:, :, :3].abs().max().item() == 0
     c2, p2, s2 = regressor_gpu(native)
     assert torch.equal(cam, c2) and torch.equal(pose, p2) and torch.equal(shape, s2)
     # a crop's result does not depend on its batch neighbours or batch size (BN is eval-mode, resnet is per-sample)
     c1, p1, s1 = regressor_gpu(xt[7:8])
-    assert torch.allclose(c1[0], cam[7], atol=1e-6) and torch.allclose(p1[0], pose[7], atol=1e-6)
+    assert torch.allclose(c1[0], cam[7], atol=2e-5) and torch.allclose(p1[0], pose[7], atol=2e-5)   # tile variants differ with B: summation order only
     with pytest.raises(ValueError):
         regressor_gpu(torch.zeros(33, 18, 256, 256, device=dev))
     with pytest.raises(ValueError):
