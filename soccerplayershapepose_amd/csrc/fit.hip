@@ -26,12 +26,13 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
     float* bb = betas + (size_t)b * 10;
     float* cb = cam + (size_t)b * 3;
     fit_init(s, r, lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb, cb,
-             joints2d + (size_t)b * 34);
+             joints2d + (size_t)b * 34, P.param_mask);
     __syncthreads();
     float* lh = loss_hist ? loss_hist + (size_t)b * P.iters : nullptr;
     float* eh = l2e_hist ? l2e_hist + (size_t)b * P.iters : nullptr;
     double b1t = 1.0, b2t = 1.0;
     const int L = P.num_levels;
+    const float w1 = (float)(1.0 - P.beta1), b2f = (float)P.beta2, w2 = (float)(1.0 - P.beta2), epsf = (float)P.eps;
     for (int it = 0; it < P.iters; ++it) {
         b1t *= P.beta1;
         b2t *= P.beta2;
@@ -43,37 +44,37 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         // each) into two barrier-free runs: 9 barriers per iteration instead of 27.
 #define STAMP(i) if (dbg && it == 2 && b == 0 && lane == 0) dbg[i] = __builtin_amdgcn_s_memtime()
         STAMP(0);
-        fit_p1(s, lane);                       __syncthreads();
+        fit_p1(s, r, lane);                       __syncthreads();
         STAMP(1);
+        fit_p2(s, lane);                          __syncthreads();
         if (wave0) {
-            fit_p2(s, lane);
 #pragma unroll
             for (int l = 1; l < kMaxLevels; ++l)       // static l: the per-lane role tables stay in registers
-                if (l < L) fit_chain_level(s, r, lane, l);
+                if (l < L) fit_chain_level(s, r, l);
         }
         STAMP(2);
         __syncthreads();
         STAMP(3);
-        fit_p4(s, lane);                       __syncthreads();
+        fit_p4(s, r, lane);                       __syncthreads();
         STAMP(4);
         if (wave0) { fit_p5(s, lane); fit_p6(s, r, lane, P); }
         STAMP(5);
         __syncthreads();
-        fit_p7(s, lane);                       __syncthreads();
+        fit_p7(s, r, lane);                       __syncthreads();
         STAMP(6);
         if (wave0) {
             fit_p8(s, lane, P, it, lh, eh);
 #pragma unroll
             for (int l = kMaxLevels - 2; l >= 0; --l)
-                if (l <= L - 2) fit_reverse_level(s, r, lane, l);
+                if (l <= L - 2) fit_reverse_level(s, r, l);
         }
         STAMP(7);
         __syncthreads();
         fit_p10(s, r, lane);                   __syncthreads();
         STAMP(8);
-        fit_p11(s, lane);                      __syncthreads();
+        fit_p11(s, r, lane);                      __syncthreads();
         STAMP(9);
-        fit_p12(s, r, lane, P, step_size, bc2_sqrt);
+        fit_p12(s, r, lane, w1, b2f, w2, epsf, step_size, bc2_sqrt);
         __syncthreads();
         STAMP(10);
     }

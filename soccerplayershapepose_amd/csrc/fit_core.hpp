@@ -23,6 +23,7 @@
 //                    dL/dvp_v = sum_k w_vk Rw_k^T h_v,   dL/dbeta = S5^T dvp + JS^T dJ
 #pragma once
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "smpl_consts.hpp"
@@ -38,9 +39,36 @@ namespace spsp {
 constexpr int kFitLanes = 256;                // lanes (threads) cooperating on one player
 constexpr int kNumPrm = SPSP_RECORD_FLOATS;   // 229: [cam(3) | R(216) | betas(10)]
 constexpr int kPrmR = 3, kPrmBeta = 219;
+constexpr int kMaxLevels = 12;                // tree depth limit (SMPL: 9 levels); checked at spsp_smpl_load
 
 // fit joint i reads output joint kFitSrc[i] (PR/config.py:38); < 24: chain joint, >= 24: face vertex (idx-24)
 #define SPSP_FIT_SRC {24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7, 8}
+
+#if defined(__HIPCC__)
+#define SPSP_UNROLL _Pragma("unroll")
+#else
+#define SPSP_UNROLL
+#endif
+
+// four consecutive floats from a 16-byte aligned address: ONE ds_read_b128 on the GPU (a lone wave issues LDS
+// instructions slowly, so the fit counts LDS instructions, not bytes)
+struct F4 { float x, y, z, w; };
+SPSP_HD F4 ld4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return F4{v.x, v.y, v.z, v.w};
+#else
+    return F4{p[0], p[1], p[2], p[3]};
+#endif
+}
+SPSP_HD void st4(float* p, float a, float b, float c, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#else
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
+SPSP_HD float dot4(const F4& a, const F4& b, float acc) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc)))); }
 
 struct FitParams {           // kernel arguments (plain data)
     int iters;
@@ -52,44 +80,63 @@ struct FitParams {           // kernel arguments (plain data)
     int num_levels;
 };
 
-struct FitShared {
+// LDS state of one player.  Float offsets of the arrays the level sweeps address by precomputed lane offsets:
+struct alignas(16) FitShared {
+    alignas(16) float W[25 * 12];      // world transforms, 3x4 row-major [R | t]; slot 24 unused
+    alignas(16) float Abar[25 * 12];   // reverse-sweep adjoints, 3x4 row-major [Bbar | abar]; slot 24 = zeros (absent child)
+    alignas(16) float Mt[24 * 16];     // forward operand: Mt[k][c] = column c of [[R_k, Jrel_k], [0, 1]]  (4 floats each)
+    alignas(16) float Tt[25 * 16];     // reverse operand: Tt[k][c] = (row c of R_k, Jrel_k[c]) for c < 3, (0,0,0,1) for c = 3
+    alignas(16) float part[256];
+    alignas(16) float part2[256];
+    alignas(16) float dvp[16];
+    alignas(16) float unit[4];         // (0, 0, 0, 1)
     float fc[kFcTotal];
-    float prm[232];
+    float prm[232];          // [cam | R(24x9) | betas]; prm[229..231] unused
+    float J[72];             // rest joints
+    float Jrel[72];          // J_k - J_parent(k) (root: J_0)
     float best[232];
     float grad[232];
-    float J[72];
-    float W[288];
     float vp[16];
     float xf[16];
-    float part[256];
-    float part2[256];
     float g[34];
     float ga[72];            // dL/d(tw_k) seeds of the chain joints that are fit targets (others stay 0; z stays 0)
     float h[16];             // dL/d(x_v) of the 5 face vertices (z stays 0)
-    int fit_src[17];         // fit joint i reads output joint fit_src[i] (PR/config.py:38)
     float rpart[17 * 5];     // per-fit-joint partials: loss, l2e, gs, gtx, gty
     float red[8];            // reduced: loss, l2e, gs, gtx, gty
-    float adir[72], abar[72], Bbar[216];
-    float dvp[16], dJ[72];
+    float adir[72];          // direct part of abar
+    float dJ[72];
     float adj[96];           // [dvp(15) | dJ_total(72) | 0(9)]: what d(beta) contracts with fc[kFcC]
     float tgt_px[34];
     float best_l2e;
     int take_best;
-    int parents[24], level_joints[24], level_start[26], child_start[25], child_list[24];
 };
 
-constexpr int kMaxLevels = 12;   // tree depth limit (SMPL: 9 levels); checked at spsp_smpl_load
-
-// Per-lane registers that live across iterations: Adam moments of parameter `lane` and this lane's ROLE in the
-// level-synchronous phases (which joint, its parent, its children), looked up ONCE.  Reading the tree tables from
-// LDS inside the loop cost 4-5 dependent LDS round trips per level (measured: ~900 cycles per phase).
+// Per-lane registers that live across iterations: Adam moments of parameter `lane`, this lane's ROLE in the
+// level-synchronous sweeps (float offsets into FitShared, looked up once), and the model constants this lane
+// multiplies with in every iteration (loop-invariant: kept in registers instead of re-read from LDS).
 struct FitLane {
     float m, v;
-    signed char ck[kMaxLevels], cp[kMaxLevels];        // forward chain, level l: joint / parent handled (or -1)
-    signed char rp[kMaxLevels], rc[kMaxLevels][3];     // reverse sweep, level l: joint and its (<= 3) children (or -1)
-    signed char par216, par72;                         // parent of joint lane/9 (P10 rotation item) / lane/3 (dJ item)
-    signed char src17;                                 // P6: source joint of fit joint `lane`
+    int trainable;
+    // forward chain, per level: offsets (in floats, relative to FitShared) or -1 when idle
+    short cw[kMaxLevels];        // output element W[k][e]
+    short cwp[kMaxLevels];       // parent row W[p][i][0]
+    short cm[kMaxLevels];        // Mt[k][c][0]
+    // reverse sweep, per level: own element and, per child slot, the child's row / T-column operands
+    short ra[kMaxLevels];        // Abar[p][i][c]  (-1: idle)
+    short rrow[kMaxLevels][3];   // Abar[ch][i][0]          (absent child: zero slot 24)
+    short rt[kMaxLevels][3];     // Tt[ch][c][0]
+    short src17;                 // P6: source joint of fit joint `lane`
+    short wp216, wp72;           // P10: parent transform offsets
+    // loop-invariant model constants
+    float cJ[11];                // P1 lanes 0..143: bias + 10 shape coefficients of J / Jrel element
+    float cP[13];                // P1: posedirs coefficients of the face-vertex coordinate this lane accumulates
+    float cS[11];                // P1 chunk 15: template + 10 shape coefficients
+    float cQ[15];                // P10: posedirs row of this lane's rotation entry
+    float cC[6];                 // P11: d(beta) coefficients
+    float w2[2], w5[5], w3[3];   // LBS weights of the face vertices used in P4 / P7
 };
+
+#define SPSP_OFF(member) ((int)(offsetof(FitShared, member) / sizeof(float)))
 
 SPSP_HD bool fit_trainable(uint32_t mask, int p) {
     if (p < kPrmR) return (mask >> 24) & 1u;
@@ -97,11 +144,13 @@ SPSP_HD bool fit_trainable(uint32_t mask, int p) {
     return (mask >> 25) & 1u;
 }
 
+SPSP_HD float* fit_f(FitShared& s) { return reinterpret_cast<float*>(&s); }
+
 // ---- one-time set-up -----------------------------------------------------------------------------------
 SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, const int* parents,
                       const int* level_joints, const int* level_start, const int* child_start,
                       const int* child_list, const float* R, const float* betas, const float* cam,
-                      const float* joints2d) {
+                      const float* joints2d, uint32_t param_mask) {
     for (int i = lane; i < kFcTotal; i += kFitLanes) s.fc[i] = fitc[i];
     if (lane < 232) {
         const int p = lane;
@@ -113,138 +162,176 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
         s.best[p] = v;
         s.grad[p] = 0.f;
     }
+    if (lane < 4) s.unit[lane] = lane == 3 ? 1.f : 0.f;
     if (lane < 34) s.tgt_px[lane] = joints2d[lane];
-    if (lane < 24) {
-        s.parents[lane] = parents[lane];
-        s.level_joints[lane] = level_joints[lane];
-        s.child_list[lane] = child_list[lane];
-    }
-    if (lane < 26) s.level_start[lane] = level_start[lane];
-    if (lane < 25) s.child_start[lane] = child_start[lane];
     if (lane == 0) { s.best_l2e = INFINITY; s.take_best = 0; }
-    {
-        const int src_tab[17] = SPSP_FIT_SRC;
-        if (lane < 17) s.fit_src[lane] = src_tab[lane];
-        if (lane < 72) s.ga[lane] = 0.f;
-        if (lane < 16) s.h[lane] = 0.f;
-        if (lane < 96) s.adj[lane] = 0.f;
+    if (lane < 72) s.ga[lane] = 0.f;
+    if (lane < 16) s.h[lane] = 0.f;
+    if (lane < 96) s.adj[lane] = 0.f;
+    for (int i = lane; i < 25 * 12; i += kFitLanes) { s.Abar[i] = 0.f; s.W[i] = 0.f; }
+    for (int i = lane; i < 25 * 16; i += kFitLanes) {       // static parts: row 3 of Mt columns, Tt[.][3] = (0,0,0,1)
+        const int c = (i >> 2) & 3, m = i & 3;
+        s.Tt[i] = (c == 3 && m == 3) ? 1.f : 0.f;
+        if (i < 24 * 16) s.Mt[i] = (c == 3 && m == 3) ? 1.f : 0.f;
     }
     r.m = r.v = 0.f;
-    // roles (the tree tables are kernel arguments in global memory here; never touched again)
-    const int slot = lane / 12;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    r.trainable = lane < kNumPrm ? (int)fit_trainable(param_mask, lane) : 0;
+
+    // ---- roles of this lane in the level sweeps (lane = slot*12 + e, e = i*4 + c) ----
+    const int slot = lane / 12, e = lane % 12, i = e >> 2, c = e & 3;
+    SPSP_UNROLL
     for (int l = 0; l < kMaxLevels; ++l) {
-        r.ck[l] = r.cp[l] = r.rp[l] = -1;
-        r.rc[l][0] = r.rc[l][1] = r.rc[l][2] = -1;
+        r.cw[l] = r.cwp[l] = r.cm[l] = r.ra[l] = -1;
+        SPSP_UNROLL
+        for (int n = 0; n < 3; ++n) { r.rrow[l][n] = (short)(SPSP_OFF(Abar) + 24 * 12); r.rt[l][n] = (short)(SPSP_OFF(Tt) + 24 * 16); }
         const int idx = level_start[l < 25 ? l : 25] + slot;
-        if (l < 25 && slot < 20 && idx < level_start[l + 1]) {
+        if (l < 25 && slot < 5 && idx < level_start[l + 1]) {
             const int k = level_joints[idx];
-            r.ck[l] = (signed char)k;
-            r.cp[l] = (signed char)parents[k];
-            r.rp[l] = (signed char)k;
+            const int p = parents[k];
+            if (p >= 0) {
+                r.cw[l] = (short)(SPSP_OFF(W) + k * 12 + e);
+                r.cwp[l] = (short)(SPSP_OFF(W) + p * 12 + i * 4);
+                r.cm[l] = (short)(SPSP_OFF(Mt) + k * 16 + c * 4);
+            }
+            r.ra[l] = (short)(SPSP_OFF(Abar) + k * 12 + e);
             const int c0 = child_start[k], nc = child_start[k + 1] - c0;
-            if (nc > 0) r.rc[l][0] = (signed char)child_list[c0];
-            if (nc > 1) r.rc[l][1] = (signed char)child_list[c0 + 1];
-            if (nc > 2) r.rc[l][2] = (signed char)child_list[c0 + 2];
+            SPSP_UNROLL
+            for (int n = 0; n < 3; ++n)
+                if (n < nc) {
+                    const int ch = child_list[c0 + n];
+                    r.rrow[l][n] = (short)(SPSP_OFF(Abar) + ch * 12 + i * 4);
+                    r.rt[l][n] = (short)(SPSP_OFF(Tt) + ch * 16 + c * 4);
+                }
         }
     }
-    r.par216 = (signed char)(lane < 216 ? parents[lane / 9] : -1);
-    r.par72 = (signed char)(lane < 72 ? parents[lane / 3] : -1);
     {
-        const int src_tab2[17] = SPSP_FIT_SRC;
-        r.src17 = (signed char)(lane < 17 ? src_tab2[lane] : 0);
+        const int src_tab[17] = SPSP_FIT_SRC;
+        r.src17 = (short)(lane < 17 ? src_tab[lane] : 0);
+    }
+    r.wp216 = (short)(lane < 216 && lane >= 9 ? SPSP_OFF(W) + parents[lane / 9] * 12 : SPSP_OFF(W));
+    r.wp72 = (short)(lane < 72 && lane >= 3 ? SPSP_OFF(W) + parents[lane / 3] * 12 : SPSP_OFF(W));
+
+    // ---- loop-invariant constants (read from the global copy of the fit constants) ----
+    SPSP_UNROLL
+    for (int t = 0; t < 11; ++t) r.cJ[t] = 0.f;
+    if (lane < 144) {
+        const int base = lane < 72 ? kFcJbar : kFcJrel, o = lane < 72 ? lane : lane - 72;
+        const int js = lane < 72 ? kFcJS : kFcJrel + 72;
+        r.cJ[0] = fitc[base + o];
+        SPSP_UNROLL
+        for (int t = 0; t < 10; ++t) r.cJ[1 + t] = fitc[js + t * kJSPitch + o];
+    }
+    {
+        const int q = lane >> 4, cc = lane & 15;
+        SPSP_UNROLL
+        for (int t = 0; t < 13; ++t) r.cP[t] = cc < 15 ? fitc[kFcP5 + (q * 13 + t) * kF5Pitch + cc] : 0.f;
+        r.cS[0] = (q == 15 && cc < 15) ? fitc[kFcVt5 + cc] : 0.f;
+        SPSP_UNROLL
+        for (int t = 0; t < 10; ++t) r.cS[1 + t] = (q == 15 && cc < 15) ? fitc[kFcS5 + t * kF5Pitch + cc] : 0.f;
+        SPSP_UNROLL
+        for (int t = 0; t < 6; ++t) r.cC[t] = cc < 10 ? fitc[kFcC + cc * kCPitch + q * 6 + t] : 0.f;
+        // P4: lane = q*16 + (v*3+i), joints 2q, 2q+1
+        const int v4 = (cc < 15 ? cc : 0) / 3;
+        SPSP_UNROLL
+        for (int t = 0; t < 2; ++t) r.w2[t] = (q < 12 && cc < 15) ? fitc[kFcW5 + v4 * 24 + q * 2 + t] : 0.f;
+    }
+    SPSP_UNROLL
+    for (int t = 0; t < 15; ++t) r.cQ[t] = (lane >= 9 && lane < 216) ? fitc[kFcP5 + (lane - 9) * kF5Pitch + t] : 0.f;
+    SPSP_UNROLL
+    for (int v = 0; v < 5; ++v) r.w5[v] = (lane >= 64 && lane < 136) ? fitc[kFcW5 + v * 24 + (lane - 64) / 3] : 0.f;
+    {
+        const int idx = lane >= 136 ? lane - 136 : 0, q = idx / 15, o = idx % 15, v = o / 3;
+        SPSP_UNROLL
+        for (int t = 0; t < 3; ++t) r.w3[t] = lane >= 136 ? fitc[kFcW5 + v * 24 + q * 3 + t] : 0.f;
     }
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------
-// P1: J = Jbar + JS.beta (lanes 0..71); partial sums of the 5 posed face vertices over 16 chunks of 13 pose
-//     features (+ template + shape term in chunk 0).  lane = q*16 + c, c = v*3+i < 15.
-//     vp = vt5 + S5.beta + sum_j P5[j] (R[9+j] - delta_j): the delta part is folded into fc[kFcVt5] at load.
-SPSP_HD void fit_p1(FitShared& s, int lane) {
+// P1: J (lanes 0..71) and J_k - J_parent (lanes 72..143) as affine functions of beta; partial sums of the 5 posed
+//     face vertices over 16 chunks of 13 pose features (lane = q*16 + c, c = v*3+i < 15; chunk 15 also carries
+//     template + shape term).  vp = vt5 + S5.beta + sum_j P5[j] (R[9+j] - delta_j): the delta part is folded into
+//     the template constant at load; row 207 of P5 is a zero pad (its factor prm[kPrmR+216] = beta[0] is finite).
+SPSP_HD void fit_p1(FitShared& s, const FitLane& r, int lane) {
     const float* beta = s.prm + kPrmBeta;
-    if (lane < 72) {
-        float acc = s.fc[kFcJbar + lane];
-        for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcJS + i * kJSPitch + lane], beta[i], acc);
-        s.J[lane] = acc;
+    float b[10];
+    SPSP_UNROLL
+    for (int i = 0; i < 10; ++i) b[i] = beta[i];
+    if (lane < 144) {
+        float acc = r.cJ[0];
+        SPSP_UNROLL
+        for (int i = 0; i < 10; ++i) acc = fmaf(r.cJ[1 + i], b[i], acc);
+        if (lane < 72) s.J[lane] = acc; else s.Jrel[lane - 72] = acc;
     }
-    const int q = lane >> 4, c = lane & 15;
-    float acc = 0.f;
-    if (c < 15) {
-        if (q == 15) {      // the shortest chunk (12 features) also carries the template + shape term
-            acc = s.fc[kFcVt5 + c];
-            for (int i = 0; i < 10; ++i) acc = fmaf(s.fc[kFcS5 + i * kF5Pitch + c], beta[i], acc);
-        }
-        // 16 x 13 = 208 rows: row 207 of P5 is a zero pad (prm[kPrmR + 216] = beta[0] is a finite dummy factor)
-        const float* P5 = s.fc + kFcP5 + (q * 13) * kF5Pitch + c;
-        const float* Rv = s.prm + kPrmR + 9 + q * 13;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int t = 0; t < 13; ++t) acc = fmaf(P5[t * kF5Pitch], Rv[t], acc);
-    }
-    s.part[lane] = acc;
+    const int q = lane >> 4;
+    float acc = r.cS[0];
+    SPSP_UNROLL
+    for (int i = 0; i < 10; ++i) acc = fmaf(r.cS[1 + i], b[i], acc);
+    const float* Rv = s.prm + kPrmR + 9 + q * 13;
+    SPSP_UNROLL
+    for (int t = 0; t < 13; ++t) acc = fmaf(r.cP[t], Rv[t], acc);
+    s.part[(lane & 15) * 16 + q] = acc;                      // [coordinate][chunk]: the finishing sum reads 4 x b128
 }
 
-// P2: finish vp (lanes 0..14: fixed-order sum of the 16 partials); root transform W_0 = [G | J_0] (lanes 16..27).
+// P2 [all lanes]: finish vp (lanes 0..14); root transform W_0 = [G | J_0] (lanes 16..27); the per-joint operands of
+//     the two level sweeps, 16 bytes each so that a sweep step is two ds_read_b128 per term:
+//     lanes 64..159:  Mt[k][c] = (R_k[0][c], R_k[1][c], R_k[2][c], 0) for c < 3, (Jrel_k, 1) for c = 3
+//     lanes 160..231: Tt[k][c] = (R_k[c][0], R_k[c][1], R_k[c][2], Jrel_k[c]),  c < 3
 SPSP_HD void fit_p2(FitShared& s, int lane) {
     if (lane < 15) {
-        float acc = 0.f;
-        for (int q = 0; q < 16; ++q) acc += s.part[q * 16 + lane];
-        s.vp[lane] = acc;
+        const float* p = s.part + lane * 16;
+        const F4 a = ld4(p), b = ld4(p + 4), c = ld4(p + 8), d = ld4(p + 12);
+        s.vp[lane] = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
     }
     if (lane >= 16 && lane < 28) {
         const int e = lane - 16, i = e >> 2, c = e & 3;
         s.W[e] = (c < 3) ? s.prm[kPrmR + i * 3 + c] : s.J[i];
     }
+    if (lane >= 64 && lane < 160) {
+        const int it = lane - 64, k = it >> 2, c = it & 3;
+        const float* R = s.prm + kPrmR + k * 9;
+        if (c < 3) st4(s.Mt + it * 4, R[c], R[3 + c], R[6 + c], 0.f);
+        else st4(s.Mt + it * 4, s.Jrel[k * 3], s.Jrel[k * 3 + 1], s.Jrel[k * 3 + 2], 1.f);
+    }
+    if (lane >= 160 && lane < 232) {
+        const int it = lane - 160, k = it / 3, c = it % 3;
+        const float* R = s.prm + kPrmR + k * 9 + c * 3;
+        st4(s.Tt + k * 16 + c * 4, R[0], R[1], R[2], s.Jrel[k * 3 + c]);
+    }
 }
 
-// P3[l]: kinematic chain, level l >= 1: W_k = W_p * [R_k | J_k - J_p]; lane = (joint slot of the level, element).
-SPSP_HD void fit_chain_level(FitShared& s, const FitLane& r, int lane, int l) {
-    const int k = r.ck[l];
-    if (k < 0) return;
-    const int p = r.cp[l];
-    const int e = lane % 12, i = e >> 2, c = e & 3;
-    const float* Rm = s.prm + kPrmR;
-    const float* Wp = s.W + p * 12 + i * 4;
-    float acc;
-    if (c < 3) {
-        acc = Wp[0] * Rm[k * 9 + c];
-        acc = fmaf(Wp[1], Rm[k * 9 + 3 + c], acc);
-        acc = fmaf(Wp[2], Rm[k * 9 + 6 + c], acc);
-    } else {
-        acc = Wp[0] * (s.J[k * 3] - s.J[p * 3]);
-        acc = fmaf(Wp[1], s.J[k * 3 + 1] - s.J[p * 3 + 1], acc);
-        acc = fmaf(Wp[2], s.J[k * 3 + 2] - s.J[p * 3 + 2], acc);
-        acc += Wp[3];
-    }
-    s.W[k * 12 + e] = acc;
+// P3[l]: kinematic chain, level l >= 1, in homogeneous form: W_k = W_p * [[R_k, Jrel_k], [0, 1]];
+//        element (i,c) = <row i of W_p (4), column c of the operand (4)>: two ds_read_b128 + 4 FMA.
+SPSP_HD void fit_chain_level(FitShared& s, const FitLane& r, int l) {
+    const int ow = r.cw[l];
+    if (ow < 0) return;
+    float* f = fit_f(s);
+    f[ow] = dot4(ld4(f + r.cwp[l]), ld4(f + r.cm[l]), 0.f);
 }
 
 // P4: face vertices x_v = sum_k w_vk (Rw_k (vp_v - J_k) + tw_k); lane = q*16 + (v*3+i), q < 12 = pair of joints.
-SPSP_HD void fit_p4(FitShared& s, int lane) {
+SPSP_HD void fit_p4(FitShared& s, const FitLane& r, int lane) {
     const int q = lane >> 4, o = lane & 15;
     if (q >= 12) return;
     float acc = 0.f;
     if (o < 15) {
         const int v = o / 3, i = o % 3;
-        for (int k = q * 2; k < q * 2 + 2; ++k) {
+        const float v0 = s.vp[v * 3], v1 = s.vp[v * 3 + 1], v2 = s.vp[v * 3 + 2];
+        SPSP_UNROLL
+        for (int t = 0; t < 2; ++t) {
+            const int k = q * 2 + t;
             const float* w = s.W + k * 12 + i * 4;
-            float t = fmaf(w[0], s.vp[v * 3] - s.J[k * 3],
-                           fmaf(w[1], s.vp[v * 3 + 1] - s.J[k * 3 + 1],
-                                fmaf(w[2], s.vp[v * 3 + 2] - s.J[k * 3 + 2], w[3])));
-            acc = fmaf(s.fc[kFcW5 + v * 24 + k], t, acc);
+            const float tt = fmaf(w[0], v0 - s.J[k * 3], fmaf(w[1], v1 - s.J[k * 3 + 1], fmaf(w[2], v2 - s.J[k * 3 + 2], w[3])));
+            acc = fmaf(r.w2[t], tt, acc);
         }
     }
-    s.part[lane] = acc;
+    s.part[o * 16 + q] = acc;
 }
 
 SPSP_HD void fit_p5(FitShared& s, int lane) {
     if (lane < 15) {
-        float acc = 0.f;
-        for (int q = 0; q < 12; ++q) acc += s.part[q * 16 + lane];
-        s.xf[lane] = acc;
+        const float* p = s.part + lane * 16;
+        const F4 a = ld4(p), b = ld4(p + 4), c = ld4(p + 8);
+        s.xf[lane] = ((a.x + a.y) + (a.z + a.w)) + (((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)));
     }
 }
 
@@ -262,6 +349,7 @@ SPSP_HD void fit_p6(FitShared& s, const FitLane& r, int lane, const FitParams& P
     const float dn_du = (2.0f * half) / P.loss_wh;           // d n / d u
     const float coef = (2.0f * P.weight) / 34.0f;            // d L / d n = coef * (n - n*)
     float loss = 0.f, l2 = 0.f, gs = 0.f, gt[2];
+    SPSP_UNROLL
     for (int c = 0; c < 2; ++c) {
         const float t = s.prm[1 + c];
         const float u = sc * (X[c] + t);
@@ -285,11 +373,12 @@ SPSP_HD void fit_p6(FitShared& s, const FitLane& r, int lane, const FitParams& P
 }
 
 // ---- backward ------------------------------------------------------------------------------------------
-// P7: reductions of P6 (lanes 0..4); lanes 64..135: direct adjoints a_k, B_k and direct dJ for item (k, i);
-//     lanes 136..255: dvp partials over 3 joints each.
-SPSP_HD void fit_p7(FitShared& s, int lane) {
+// P7: reductions of P6 (lanes 0..4); lanes 64..135: direct adjoints of item (k, i): row i of [B_k | a_k] and the
+//     direct dJ[k][i]; lanes 136..255: dvp partials over 3 joints each.
+SPSP_HD void fit_p7(FitShared& s, const FitLane& r, int lane) {
     if (lane < 5) {
         float acc = 0.f;
+        SPSP_UNROLL
         for (int i = 0; i < 17; ++i) acc += s.rpart[i * 5 + lane];
         s.red[lane] = acc;
     }
@@ -297,19 +386,21 @@ SPSP_HD void fit_p7(FitShared& s, int lane) {
         const int it = lane - 64, k = it / 3, i = it % 3;
         float a = s.ga[it];
         float b0 = 0.f, b1 = 0.f, b2 = 0.f, dj = 0.f;
+        const float j0 = s.J[k * 3], j1 = s.J[k * 3 + 1], j2 = s.J[k * 3 + 2];
+        const float wki = s.W[k * 12 + i], wki4 = s.W[k * 12 + 4 + i];
+        SPSP_UNROLL
         for (int v = 0; v < 5; ++v) {
-            const float w = s.fc[kFcW5 + v * 24 + k];
+            const float w = r.w5[v];
             const float wh = w * s.h[v * 3 + i];
             a += wh;
-            b0 = fmaf(wh, s.vp[v * 3] - s.J[k * 3], b0);
-            b1 = fmaf(wh, s.vp[v * 3 + 1] - s.J[k * 3 + 1], b1);
-            b2 = fmaf(wh, s.vp[v * 3 + 2] - s.J[k * 3 + 2], b2);
+            b0 = fmaf(wh, s.vp[v * 3] - j0, b0);
+            b1 = fmaf(wh, s.vp[v * 3 + 1] - j1, b1);
+            b2 = fmaf(wh, s.vp[v * 3 + 2] - j2, b2);
             // direct dJ[k][l = i] = -sum_v w_vk sum_i' Rw_k[i'][l] h_v[i']   (h_v[2] == 0)
-            dj = fmaf(w, fmaf(s.W[k * 12 + i], s.h[v * 3], s.W[k * 12 + 4 + i] * s.h[v * 3 + 1]), dj);
+            dj = fmaf(w, fmaf(wki, s.h[v * 3], wki4 * s.h[v * 3 + 1]), dj);
         }
         s.adir[it] = a;
-        s.abar[it] = a;
-        s.Bbar[k * 9 + i * 3] = b0; s.Bbar[k * 9 + i * 3 + 1] = b1; s.Bbar[k * 9 + i * 3 + 2] = b2;
+        st4(s.Abar + k * 12 + i * 4, b0, b1, b2, a);
         s.dJ[it] = -dj;
     }
     if (lane >= 136) {   // dvp[v][l] partial over joints 3q..3q+2: sum_k w_vk sum_i Rw_k[i][l] h_v[i]
@@ -317,17 +408,20 @@ SPSP_HD void fit_p7(FitShared& s, int lane) {
         const int v = o / 3, l = o % 3;
         const float h0 = s.h[v * 3], h1 = s.h[v * 3 + 1];
         float acc = 0.f;
-        for (int k = q * 3; k < q * 3 + 3; ++k)
-            acc = fmaf(s.fc[kFcW5 + v * 24 + k], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
-        s.part2[q * 16 + o] = acc;
+        SPSP_UNROLL
+        for (int t = 0; t < 3; ++t) {
+            const int k = q * 3 + t;
+            acc = fmaf(r.w3[t], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
+        }
+        s.part2[o * 16 + q] = acc;
     }
 }
 
 // P8: finish dvp; lane 63 turns the reductions into loss / l2e, history and the best-iterate decision.
 SPSP_HD void fit_p8(FitShared& s, int lane, const FitParams& P, int it, float* loss_hist, float* l2e_hist) {
     if (lane < 15) {
-        float acc = 0.f;
-        for (int q = 0; q < 8; ++q) acc += s.part2[q * 16 + lane];
+        const F4 a = ld4(s.part2 + lane * 16), b = ld4(s.part2 + lane * 16 + 4);
+        const float acc = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
         s.dvp[lane] = acc;
         s.adj[lane] = acc;
     }
@@ -342,68 +436,52 @@ SPSP_HD void fit_p8(FitShared& s, int lane, const FitParams& P, int it, float* l
     }
 }
 
-// P9[l]: reverse sweep -- every joint p of level l gathers from its children (level l+1, already final).
-SPSP_HD void fit_reverse_level(FitShared& s, const FitLane& r, int lane, int l) {
-    const int p = r.rp[l];
-    if (p < 0) return;
-    const int e = lane % 12;
-    const float* Rm = s.prm + kPrmR;
-    if (e < 3) {
-        float acc = s.abar[p * 3 + e];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int n = 0; n < 3; ++n) {
-            const int ch = r.rc[l][n];
-            if (ch >= 0) acc += s.abar[ch * 3 + e];
-        }
-        s.abar[p * 3 + e] = acc;
-    } else {
-        const int i = (e - 3) / 3, c = (e - 3) % 3;
-        float acc = s.Bbar[p * 9 + i * 3 + c];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int n = 0; n < 3; ++n) {
-            const int ch = r.rc[l][n];
-            if (ch < 0) continue;
-            acc = fmaf(s.abar[ch * 3 + i], s.J[ch * 3 + c] - s.J[p * 3 + c], acc);
-            const float* Bc = s.Bbar + ch * 9 + i * 3;
-            const float* Rc = Rm + ch * 9 + c * 3;     // row c of R_child:  (Bbar_c R_c^T)[i][c] = sum_m Bbar_c[i][m] R_c[c][m]
-            acc = fmaf(Bc[0], Rc[0], fmaf(Bc[1], Rc[1], fmaf(Bc[2], Rc[2], acc)));
-        }
-        s.Bbar[p * 9 + i * 3 + c] = acc;
-    }
+// P9[l]: reverse sweep in homogeneous form.  With Abar_k = [Bbar_k | abar_k] (3x4):
+//   Abar_p += sum over children ch of  Abar_ch * [[R_ch^T, 0], [Jrel_ch^T, 1]]
+//   element (i,c) += <row i of Abar_ch (4), Tt[ch][c] (4)>: two ds_read_b128 + 4 FMA per child.
+//   Absent children point at the all-zero slot 24 of Abar.
+SPSP_HD void fit_reverse_level(FitShared& s, const FitLane& r, int l) {
+    const int oa = r.ra[l];
+    if (oa < 0) return;
+    float* f = fit_f(s);
+    float acc = f[oa];
+    SPSP_UNROLL
+    for (int n = 0; n < 3; ++n) acc = dot4(ld4(f + r.rrow[l][n]), ld4(f + r.rt[l][n]), acc);
+    f[oa] = acc;
 }
 
 // P10: rotation gradients incl. the pose-blend-shape path through the face vertices (lanes 0..215) and the
 //      total dJ (lanes 0..71, after their rotation item).
 SPSP_HD void fit_p10(FitShared& s, const FitLane& r, int lane) {
+    float* f = fit_f(s);
     if (lane < 216) {                                        // item (k, l, c): dR_k[l][c]
         const int k = lane / 9, e = lane % 9, l = e / 3, c = e % 3;
         float acc;
-        if (k == 0) acc = s.Bbar[e];
+        if (k == 0) acc = s.Abar[l * 4 + c];
         else {
-            const float* Wp = s.W + r.par216 * 12;
-            acc = Wp[l] * s.Bbar[k * 9 + c];
-            acc = fmaf(Wp[4 + l], s.Bbar[k * 9 + 3 + c], acc);
-            acc = fmaf(Wp[8 + l], s.Bbar[k * 9 + 6 + c], acc);
-            const float* P5 = s.fc + kFcP5 + ((k - 1) * 9 + e) * kF5Pitch;
-            for (int o = 0; o < 15; ++o) acc = fmaf(P5[o], s.dvp[o], acc);
+            const float* Wp = f + r.wp216;
+            const float* A = s.Abar + k * 12 + c;
+            acc = Wp[l] * A[0];
+            acc = fmaf(Wp[4 + l], A[4], acc);
+            acc = fmaf(Wp[8 + l], A[8], acc);
+            const F4 d0 = ld4(s.dvp), d1 = ld4(s.dvp + 4), d2 = ld4(s.dvp + 8), d3 = ld4(s.dvp + 12);
+            const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+            SPSP_UNROLL
+            for (int o = 0; o < 15; ++o) acc = fmaf(r.cQ[o], dv[o], acc);
         }
         s.grad[kPrmR + lane] = acc;
     }
     if (lane < 72) {                                         // dJ_total[k][l]
         const int k = lane / 3, l = lane % 3;
+        const float* A = s.Abar + k * 12 + 3;                // abar_k[i] = A[4 i]
         float acc = s.dJ[lane];
-        if (k == 0) acc += s.abar[l];
+        if (k == 0) acc += A[4 * l];
         else {
-            const float* Wp = s.W + r.par72 * 12;
-            acc = fmaf(Wp[l], s.abar[k * 3], fmaf(Wp[4 + l], s.abar[k * 3 + 1], fmaf(Wp[8 + l], s.abar[k * 3 + 2], acc)));
+            const float* Wp = f + r.wp72;
+            acc = fmaf(Wp[l], A[0], fmaf(Wp[4 + l], A[4], fmaf(Wp[8 + l], A[8], acc)));
         }
         const float* Wk = s.W + k * 12;
-        const float c0 = s.abar[k * 3] - s.adir[k * 3], c1 = s.abar[k * 3 + 1] - s.adir[k * 3 + 1],
-                    c2 = s.abar[k * 3 + 2] - s.adir[k * 3 + 2];
+        const float c0 = A[0] - s.adir[k * 3], c1 = A[4] - s.adir[k * 3 + 1], c2 = A[8] - s.adir[k * 3 + 2];
         acc -= fmaf(Wk[l], c0, fmaf(Wk[4 + l], c1, Wk[8 + l] * c2));
         s.adj[15 + lane] = acc;
     }
@@ -411,37 +489,32 @@ SPSP_HD void fit_p10(FitShared& s, const FitLane& r, int lane) {
 
 // P11: d beta partials over 16 chunks of 6 of the adjoint vector adj = [dvp(15) | dJ_total(72) | 0(9)];
 //      lane = q*16 + i, i < 10.
-SPSP_HD void fit_p11(FitShared& s, int lane) {
-    const int q = lane >> 4, i = lane & 15;
+SPSP_HD void fit_p11(FitShared& s, const FitLane& r, int lane) {
+    const int q = lane >> 4;
+    const float* A = s.adj + q * 6;
     float acc = 0.f;
-    if (i < 10) {
-        const float* C = s.fc + kFcC + i * kCPitch + q * 6;
-        const float* A = s.adj + q * 6;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int t = 0; t < 6; ++t) acc = fmaf(C[t], A[t], acc);
-    }
-    s.part[lane] = acc;
+    SPSP_UNROLL
+    for (int t = 0; t < 6; ++t) acc = fmaf(r.cC[t], A[t], acc);
+    s.part[(lane & 15) * 16 + q] = acc;
 }
 
 // P12: best-iterate snapshot (pre-step parameters) and the torch.optim.Adam step (single-tensor path), one
 //   parameter per lane:
 //   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(1-b2^t) + eps; p += (-lr/(1-b1^t) * m) / denom
-SPSP_HD void fit_p12(FitShared& s, FitLane& r, int lane, const FitParams& P, float step_size, float bc2_sqrt) {
+SPSP_HD void fit_p12(FitShared& s, FitLane& r, int lane, float w1, float b2, float w2, float eps, float step_size,
+                     float bc2_sqrt) {
     const int p = lane;
     if (p >= kNumPrm) return;
-    const float w1 = (float)(1.0 - P.beta1), b2 = (float)P.beta2, w2 = (float)(1.0 - P.beta2), eps = (float)P.eps;
     const float cur = s.prm[p];
     if (s.take_best) s.best[p] = cur;
-    if (!fit_trainable(P.param_mask, p)) return;
+    if (!r.trainable) return;
     float g;
     if (p < kPrmR) g = s.red[2 + p];
     else if (p < kPrmBeta) g = s.grad[p];
     else {
-        const int i = p - kPrmBeta;
-        g = 0.f;
-        for (int q = 0; q < 16; ++q) g += s.part[q * 16 + i];
+        const float* pp = s.part + (p - kPrmBeta) * 16;
+        const F4 a = ld4(pp), b = ld4(pp + 4), c = ld4(pp + 8), d = ld4(pp + 12);
+        g = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
     }
     r.m = r.m + w1 * (g - r.m);
     r.v = r.v * b2 + (w2 * g) * g;

@@ -26,6 +26,7 @@ constexpr int kFcW5 = kFcP5 + 208 * kF5Pitch;             // [5][24]    lbs weig
 constexpr int kCPitch = 97;
 constexpr int kFcC = kFcW5 + 120;                         // [10][97]   d(beta) coefficients over the 96-long adjoint
                                                           //            [dvp(15) | dJ(72) | 0(9)]: S5 | JS | 0
-constexpr int kFcTotal = kFcC + 10 * kCPitch;             // 5614 floats = 22.5 KB
+constexpr int kFcJrel = kFcC + 10 * kCPitch;              // [72 + 10*73]  same as Jbar/JS for J_k - J_parent(k) (root: J_0)
+constexpr int kFcTotal = kFcJrel + 72 + 10 * kJSPitch;    // 6416 floats = 25.7 KB
 
 }  // namespace spsp

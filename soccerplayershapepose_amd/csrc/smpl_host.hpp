@@ -131,6 +131,14 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
         for (int o = 0; o < 15; ++o) h.fitc[kFcC + i * kCPitch + o] = h.fitc[kFcS5 + i * kF5Pitch + o];
         for (int o = 0; o < 72; ++o) h.fitc[kFcC + i * kCPitch + 15 + o] = h.fitc[kFcJS + i * kJSPitch + o];
     }
+    // relative rest joints J_k - J_parent(k) as affine functions of beta (root: J_0 itself)
+    for (int k = 0; k < kNJ; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const int o = k * 3 + c, po = a.parents[k] * 3 + c;
+            h.fitc[kFcJrel + o] = h.jconst[o] - (k ? h.jconst[po] : 0.f);
+            for (int i = 0; i < kNB; ++i)
+                h.fitc[kFcJrel + 72 + i * kJSPitch + o] = h.jconst[72 + i * 72 + o] - (k ? h.jconst[72 + i * 72 + po] : 0.f);
+        }
     // The pose feature is R[1:] - I; the kernel contracts posedirs with R directly, so the identity part
     // (-sum over the diagonal entries j % 9 in {0,4,8}) is folded into the template term once, in float64.
     for (int c = 0; c < 15; ++c) {

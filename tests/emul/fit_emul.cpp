@@ -36,7 +36,7 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
         FitLane r[kFitLanes];
         float* Rb = R + (size_t)b * 216; float* bb = betas + (size_t)b * 10; float* cb = cam + (size_t)b * 3;
         ALL_LANES(fit_init(s, r[lane], lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb,
-                           cb, joints2d + (size_t)b * 34));
+                           cb, joints2d + (size_t)b * 34, param_mask));
         float* lh = loss_hist ? loss_hist + (size_t)b * iters : nullptr;
         float* eh = l2e_hist ? l2e_hist + (size_t)b * iters : nullptr;
         double b1t = 1.0, b2t = 1.0;
@@ -45,25 +45,25 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
             b1t *= beta1; b2t *= beta2;
             const float step_size = (float)(lr / (1.0 - b1t));
             const float bc2_sqrt = (float)std::sqrt(1.0 - b2t);
-            ALL_LANES(fit_p1(s, lane));
+            ALL_LANES(fit_p1(s, r[lane], lane));
             ALL_LANES(fit_p2(s, lane));
-            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], lane, l)); }
-            ALL_LANES(fit_p4(s, lane));
+            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], l)); }
+            ALL_LANES(fit_p4(s, r[lane], lane));
             ALL_LANES(fit_p5(s, lane));
             ALL_LANES(fit_p6(s, r[lane], lane, P));
-            ALL_LANES(fit_p7(s, lane));
+            ALL_LANES(fit_p7(s, r[lane], lane));
             ALL_LANES(fit_p8(s, lane, P, it, lh, eh));
-            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], lane, l)); }
+            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], l)); }
             ALL_LANES(fit_p10(s, r[lane], lane));
-            ALL_LANES(fit_p11(s, lane));
+            ALL_LANES(fit_p11(s, r[lane], lane));
             if (it == 0 && grad_first) {      // gradient of the first iteration, record order [cam|R|betas]
                 float* g = grad_first + (size_t)b * kNumPrm;
                 for (int p = 0; p < kNumPrm; ++p)
                     g[p] = p < kPrmR ? s.red[2 + p]
                          : p < kPrmBeta ? s.grad[p]
-                         : [&] { float t = 0.f; for (int q = 0; q < 16; ++q) t += s.part[q * 16 + (p - kPrmBeta)]; return t; }();
+                         : [&] { float t = 0.f; for (int q = 0; q < 16; ++q) t += s.part[(p - kPrmBeta) * 16 + q]; return t; }();
             }
-            ALL_LANES(fit_p12(s, r[lane], lane, P, step_size, bc2_sqrt));
+            ALL_LANES(fit_p12(s, r[lane], lane, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt));
         }
         const float* src = (select_mode == SPSP_FIT_SELECT_BEST_L2E) ? s.best : s.prm;
         for (int p = 0; p < kNumPrm; ++p) {
