@@ -73,8 +73,14 @@ inline float bf16_to_f32_host(uint16_t h) {
 // ---- optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg ------------
 namespace spsp {
 enum KernelId {
-    kKConv1 = 0, kKMaxpool, kKConvL1, kKConvL2, kKConvL3, kKConvL4, kKIefFc, kKIefMisc, kKProxyPack,
-    kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKNumKernels
+    kKConv1Patch = 0, kKConv1Igemm, kKMaxpool,
+    kKPatchW16Small,   // conv3x3_patch_kernel<false, 1, 3>  (4-wave workgroups)
+    kKPatchW16Big,     // conv3x3_patch_kernel<false, 2, 5>  (8-wave workgroups)
+    kKPatchW8Small,    // conv3x3_patch_kernel<true, 1, 3>
+    kKPatchW8Big,      // conv3x3_patch_kernel<true, 2, 5>
+    kKConvRing,        // conv_ring_kernel<...> (stride-2 / 1x1 convs, fallbacks)
+    kKConvIgemm,       // conv_igemm_kernel<...> (first generation, fallbacks)
+    kKIefFc, kKIefMisc, kKProxyPack, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKNumKernels
 };
 struct ProfRec { int id; hipEvent_t start, stop; };
 }  // namespace spsp

@@ -39,10 +39,12 @@ void spsp_destroy(spsp_ctx* ctx) {
 }
 
 static const char* const kKernelNames[spsp::kKNumKernels] = {
-    "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel", "conv_igemm_kernel<128, 64, 64, 16>",
-    "conv_igemm_kernel<128, 128, 64, 16>", "conv_igemm_kernel<64, 128, 64, 16>", "conv_igemm_kernel<64, 64, 64, 16>",
-    "fc_kernel", "init_params_kernel+split_params_kernel", "proxy_pack_kernel", "rot6d_kernel", "fit_kernel",
-    "smpl_chain_kernel", "smpl_skin_kernel", "smpl_extra_joints_kernel"};
+    "conv1_patch_kernel", "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel",
+    "conv3x3_patch_kernel<false, 1, 3>", "conv3x3_patch_kernel<false, 2, 5>",
+    "conv3x3_patch_kernel<true, 1, 3>", "conv3x3_patch_kernel<true, 2, 5>",
+    "conv_ring_kernel", "conv_igemm_kernel", "fc_kernel", "init_params_kernel+split_params_kernel",
+    "proxy_pack_kernel", "rot6d_kernel", "fit_kernel", "smpl_chain_kernel", "smpl_skin_kernel",
+    "smpl_extra_joints_kernel"};
 
 int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
 const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernelNames[id] : nullptr; }

@@ -42,7 +42,11 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         // wave issues its LDS instructions in order, so a ds_write is visible to the following ds_read of any lane
         // of the same wave.  That folds the 8 + 8 level-synchronous chain / reverse-sweep steps (<= 60 active lanes
         // each) into two barrier-free runs: 9 barriers per iteration instead of 27.
+#ifdef SPSP_FIT_STAMPS      // diagnostic build only: per-phase s_memtime stamps of iteration 2, player 0
 #define STAMP(i) if (dbg && it == 2 && b == 0 && lane == 0) dbg[i] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i)
+#endif
         STAMP(0);
         fit_p1(s, r, lane);                       __syncthreads();
         STAMP(1);
@@ -138,7 +142,9 @@ int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, 
     P.num_levels = s->num_levels;
     ProfScope ps(ctx, kKFit, as_stream(stream));
     unsigned long long* dbg = nullptr;
+#ifdef SPSP_FIT_STAMPS
     if (getenv("SPSP_FIT_DEBUG")) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
+#endif
     fit_kernel<<<B, kFitLanes, 0, as_stream(stream)>>>(P, s->fitc, s->parents, s->level_joints, s->d_level_start,
                                                 s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist,
                                                 l2e_hist, dbg);

@@ -235,9 +235,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     a.relu = relu;
     a.splitk = 1;
     if (L >= 0 && r->use_patch && conv_patch_supported(a)) {
-        const int kid3 = L == 0 ? kKConvL1 : L == 1 ? kKConvL2 : L == 2 ? kKConvL3 : kKConvL4;
+        const int v = r->patch_variant[L];
+        const int kid3 = a.Wo == 8 ? (v ? kKPatchW8Big : kKPatchW8Small) : (v ? kKPatchW16Big : kKPatchW16Small);
         ProfScope ps(ctx, kid3, st);
-        return launch_conv_patch(a, r->patch_variant[L], st);
+        return launch_conv_patch(a, v, st);
     }
     if (L >= 0 && r->ring[L] != kRingNone) {
         const RingTile rt = r->ring[L];
@@ -248,17 +249,15 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
             while (sk > 1 && (a.nsteps / sk < 4 || (size_t)sk * a.M * a.N > r->slab_floats)) sk >>= 1;
             a.splitk = sk;
             a.part = r->slab;
-            const int kid2 = L == 0 ? kKConvL1 : L == 1 ? kKConvL2 : L == 2 ? kKConvL3 : kKConvL4;
-            ProfScope ps(ctx, kid2, st);
+            ProfScope ps(ctx, kKConvRing, st);
             return launch_conv_ring(a, rt, st);
         }
     }
     if (ci == 0 && r->conv1_patch) {
-        ProfScope ps(ctx, kKConv1, st);
+        ProfScope ps(ctx, kKConv1Patch, st);
         return launch_conv1_patch(a, st);
     }
-    const int kid = tile == kTileConv1 ? kKConv1 : tile == kTile128x64 ? kKConvL1 : tile == kTile128x128 ? kKConvL2
-                  : tile == kTile64x128 ? kKConvL3 : kKConvL4;
+    const int kid = tile == kTileConv1 ? kKConv1Igemm : kKConvIgemm;
     ProfScope ps(ctx, kid, st);
     return launch_conv(a, tile, st);
 }

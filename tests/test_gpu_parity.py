@@ -234,14 +234,15 @@ def test_fit_is_deterministic_and_batch_independent(smpl_gpu, dev):
 
 
 # ---------------------------------------------------------------- regressor (a2-a4)
-def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_sd_np, dev):
+@pytest.mark.parametrize('B', [3, 8])    # 3: ragged, layer4 falls back to the ring kernel; 8: every patch kernel incl. the 8x8 one
+def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_sd_np, dev, B):
     from oracle import regressor as OR
-    x, _ = S.proxy_crops(3, seed=4)
+    x, _ = S.proxy_crops(B, seed=4)
     cam, pose, shape, feats = regressor_gpu(torch.from_numpy(x).to(dev), return_feats=True)
     f_emu, stages = OR.encoder_forward(regressor_sd_np, x, emulate_bf16=True, return_stages=True)
     names = ['conv1', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4']
     for si, n in enumerate(names):
-        got = regressor_gpu.read_stage(si, 3).cpu()
+        got = regressor_gpu.read_stage(si, B).cpu()
         ref = stages[n]
         assert got.shape == ref.shape
         err = (got - ref).abs().max().item()
