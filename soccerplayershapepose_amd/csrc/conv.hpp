@@ -28,6 +28,7 @@ struct ConvArgs {
     int relu;
     float* part;             // split-K: fp32 slabs [splitk][M][N] (conv_ring only)
     int splitk;              // 1 = no split
+    unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of workgroup 0
 };
 
 enum ConvTile { kTile128x64 = 0, kTile128x128, kTile64x128, kTile64x64, kTileConv1 };

@@ -143,12 +143,15 @@ __global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
         }
     }
 
-    // ---- epilogue: bias + ReLU -> bf16 NHWC (1-px bordered output) ----
-    const int oy = oy0 + ry;
+    // ---- epilogue: bias + ReLU -> bf16, staged through LDS so every global store is a whole 128-byte line
+    //      (a lane owns 4 channels = 8 B of a pixel; stored directly a wave-instruction touches a quarter of 16 lines).
+    //      Output tile [512 px][128 B], 16-byte chunk XOR-swizzled by the pixel; tile pixel tp = wave*64 + j*16 + frow
+    //      = (row tp / 128, column tp % 128).
+    __syncthreads();                                       // patch and ring are dead
+    unsigned char* const outT = smem;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int ox = half * 64 + j * 16 + frow;
-        const size_t obase = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)oy * a.out_row + (size_t)ox * a.out_pix;
+        const int tp = wave * 64 + j * 16 + frow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = i * 16 + fq * 4;
@@ -156,8 +159,17 @@ __global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
             const f32x4 c = acc[i][j];
             float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
             if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            *reinterpret_cast<uint2*>(outT + tp * 128 + (((i * 2 + (fq >> 1)) ^ (tp & 7)) * 16) + (fq & 1) * 8) =
+                make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {                       // 512 px x 8 chunks / 512 threads
+        const int idx = tid + it * 512, tp = idx >> 3, c = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(outT + tp * 128 + ((c ^ (tp & 7)) * 16));
+        const size_t o = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)(oy0 + (tp >> 7)) * a.out_row + (size_t)(tp & 127) * a.out_pix;
+        *reinterpret_cast<uint4*>(a.out + o + c * 8) = v;
     }
 }
 

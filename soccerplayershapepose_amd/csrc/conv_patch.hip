@@ -25,6 +25,7 @@
 // the rest was this wave's own VALU + LDS latency + barriers, serialised in front of its MFMAs.)  The patch of
 // the next 64-channel chunk can therefore only be fetched after the last tap of the current one; the partner
 // workgroup covers that bubble.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv.hpp"
@@ -58,6 +59,12 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int kWStage = 64 * 128;            // [64 n][64 k] bf16
+
+#ifdef SPSP_CONV_STAMPS
+#define CSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
+#else
+#define CSTAMP(i)
+#endif
 constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
 
 template <bool W8, int KS, int NS>
@@ -173,75 +180,104 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     // matrix is stored tap-major/chunk-minor like the implicit-GEMM kernels, so step (ch, tap) reads K-step
     // g = tap * nchunks + ch.
     const int nsteps = 9 * nchunks;
-    auto gstep = [&](int s) { const int ch = s / 9, tap = s - ch * 9; return tap * nchunks + ch; };
+    constexpr int NK = 2 / KS;                          // 32-deep k-substeps this wave does per step
 
+    // ---- software pipeline: the fragment reads of step s are issued BEFORE the MFMAs of step s-1, so the LDS
+    // latency (measured: ~380 cycles per step, as much as the MFMAs themselves) hides under the matrix pipe.  Two
+    // register sets alternate; a step's set is static because the tap loop is fully unrolled and 9 is odd
+    // (set = (9 ch + tap) & 1).  Per step s:
+    //   lgkmcnt(0)            fragments of step s-1 have arrived (which also frees the ring slot / patch they came from)
+    //   vmcnt(..) + barrier   weight stage s has landed, for every wave
+    //   issue LDS-DMA         weight stage s + NS-1 into the slot of stage s-1
+    //   ds_read x (8 NK)      fragments of step s     -> set s & 1
+    //   MFMA x (16 NK)        step s-1                <- the other set
+    // (macros, not lambdas: the fragment arrays must be indexed by literal constants to stay in registers)
+    bf16x8 wfr[2][NK][4], xfr[2][NK][4];
+#define SPSP_READ_FRAGS(TAP, SET, SLOT)                                                                   \
+    {                                                                                                     \
+        const uint32_t wbase_ = smem_base + (SLOT) * kWStage;                                             \
+        _Pragma("unroll") for (int kk = 0; kk < NK; ++kk) {                                               \
+            const int ks_ = KS == 2 ? kw : kk;                                                            \
+            const uint32_t wa_ = wbase_ + (w_lane ^ (ks_ * 64));                                          \
+            wfr[SET][kk][0] = lds_read_b128<0>(wa_);                                                      \
+            wfr[SET][kk][1] = lds_read_b128<2048>(wa_);                                                   \
+            wfr[SET][kk][2] = lds_read_b128<4096>(wa_);                                                   \
+            wfr[SET][kk][3] = lds_read_b128<6144>(wa_);                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+                xfr[SET][kk][j] = lds_read_b128<0>(KS == 2 ? xoff[TAP][j] : (xoff[TAP][j] ^ (kk * 64)));  \
+        }                                                                                                 \
+    }
+#define SPSP_MFMA_SET(SET)                                                                                \
+    {                                                                                                     \
+        _Pragma("unroll") for (int kk = 0; kk < NK; ++kk)                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j], 0, 0, 0); \
+    }
+    // wait until weight stage s has landed: `ahead` younger stages (LPS pieces each) may stay in flight
+    auto wait_stage = [&](int ahead) {
+        if (ahead >= 3 && kNS >= 5) wait_vmcnt<3 * LPS>();
+        else if (ahead == 2 && kNS >= 4) wait_vmcnt<2 * LPS>();
+        else if (ahead >= 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+    };
+
+    CSTAMP(0);
     issue_patch(0);
     int issued = 0;
-    for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w(gstep(issued), issued);
-    int s = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++s) {
-            const int ahead = issued - (s + 1);
-            if (ahead >= 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (tap == 0 && ch > 0) {
-                // every wave is past its last read of the previous chunk's patch: refill it, then wait for it
-                // (the weight stage issued below is younger, so vmcnt(LPS) covers the patch pieces)
-                issue_patch(ch);
-                if (issued < nsteps) { issue_w(gstep(issued), issued % kNS); ++issued; wait_vmcnt<LPS>(); }
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-            } else if (issued < nsteps) { issue_w(gstep(issued), issued % kNS); ++issued; }
-
-            const uint32_t wbase = smem_base + (s % kNS) * kWStage;
-            if constexpr (KS == 1) {
-                bf16x8 wf[2][4], xf[2][4];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const uint32_t wa = wbase + (w_lane ^ (ks * 64));
-                    wf[ks][0] = lds_read_b128<0>(wa);
-                    wf[ks][1] = lds_read_b128<2048>(wa);
-                    wf[ks][2] = lds_read_b128<4096>(wa);
-                    wf[ks][3] = lds_read_b128<6144>(wa);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xf[ks][j] = lds_read_b128<0>(xoff[tap][j] ^ (ks * 64));
-                }
-                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);
-            } else {
-                // this wave's half of the step (k = 32*kw .. 32*kw+31); its SIMD partner wave does the other half
-                bf16x8 wf[4], xf[4];
-                const uint32_t wa = wbase + (w_lane ^ (kw * 64));
-                wf[0] = lds_read_b128<0>(wa);
-                wf[1] = lds_read_b128<2048>(wa);
-                wf[2] = lds_read_b128<4096>(wa);
-                wf[3] = lds_read_b128<6144>(wa);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] = lds_read_b128<0>(xoff[tap][j]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-            }
+    for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w((issued % 9) * nchunks + issued / 9, issued);
+    auto issue_next = [&]() {
+        if (issued < nsteps) {
+            const int ich = issued / 9, itap = issued - ich * 9;
+            issue_w(itap * nchunks + ich, issued % kNS);
+            ++issued;
         }
-    }
+    };
 
+#define SPSP_STEP(TAP, SET, CH, S)                                                                        \
+    {                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        wait_stage(min(issued - ((S) + 1), kNS - 2));                                                     \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if ((TAP) == 0 && (CH) > 0) {                                                                     \
+            /* chunk boundary: every wave is past its last read of the old patch.  Refill it; the MFMAs of the */ \
+            /* previous step run while it is in flight (patch pieces are older than the stage issued after).  */ \
+            issue_patch(CH);                                                                              \
+            issue_next();                                                                                 \
+            SPSP_MFMA_SET((SET) ^ 1)                                                                      \
+            if (issued - ((S) + 1) >= 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();                         \
+            __builtin_amdgcn_s_barrier();                                                                 \
+            SPSP_READ_FRAGS(TAP, SET, (S) % kNS)                                                          \
+        } else {                                                                                          \
+            issue_next();                                                                                 \
+            SPSP_READ_FRAGS(TAP, SET, (S) % kNS)                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            if ((TAP) > 0 || (S) > 0) SPSP_MFMA_SET((SET) ^ 1)                                            \
+        }                                                                                                 \
+    }
+#define SPSP_CHUNK(P0, CH)                                                                                \
+    {                                                                                                     \
+        const int s0_ = (CH) * 9;                                                                         \
+        SPSP_STEP(0, (0 + P0) & 1, CH, s0_ + 0) SPSP_STEP(1, (1 + P0) & 1, CH, s0_ + 1)                    \
+        SPSP_STEP(2, (2 + P0) & 1, CH, s0_ + 2) SPSP_STEP(3, (3 + P0) & 1, CH, s0_ + 3)                    \
+        SPSP_STEP(4, (4 + P0) & 1, CH, s0_ + 4) SPSP_STEP(5, (5 + P0) & 1, CH, s0_ + 5)                    \
+        SPSP_STEP(6, (6 + P0) & 1, CH, s0_ + 6) SPSP_STEP(7, (7 + P0) & 1, CH, s0_ + 7)                    \
+        SPSP_STEP(8, (8 + P0) & 1, CH, s0_ + 8)                                                            \
+    }
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        SPSP_CHUNK(0, ch)
+        if (ch + 1 < nchunks) SPSP_CHUNK(1, ch + 1)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if ((nsteps - 1) & 1) SPSP_MFMA_SET(1) else SPSP_MFMA_SET(0)
+#undef SPSP_CHUNK
+#undef SPSP_STEP
+#undef SPSP_MFMA_SET
+#undef SPSP_READ_FRAGS
+
+    CSTAMP(4);
     if constexpr (KS == 2) {
         // Combine the two K-halves: wave (kw, w) keeps channel tiles i = 2kw, 2kw+1 and hands the other two to its
         // partner through LDS (ring + patch are dead by now; 8 waves x 8 KB).  Static register indices only.
@@ -269,8 +305,31 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         if (kw == 0) get(std::integral_constant<int, 0>{}); else get(std::integral_constant<int, 2>{});
     }
 
-    // ---- epilogue: lane = pixel (frow of tile j), 4 consecutive channels per accumulator; this wave finalises
-    //      channel tiles I0 .. I0 + 4/KS - 1 ----
+    // ---- epilogue, staged through LDS so that HBM sees whole 128-byte lines ----
+    // In the accumulator a lane owns 4 channels (8 B) of a pixel: stored directly, one wave-instruction touches a
+    // quarter of 16 different lines (measured: 10-20 k cycles per workgroup, more than the whole K loop).  Instead:
+    //   A  residual tile  global -> LDS   (16 B per lane, 8 lanes = one pixel's 128-B channel block)
+    //   C  per-lane math, residual from LDS, packed bf16 into an LDS output tile
+    //   E  output tile    LDS -> global   (16 B per lane, whole lines)
+    // LDS tiles are [256 px][128 B] with the 16-byte chunk XOR-swizzled by the pixel (bank-conflict-free both ways).
+    // tile pixel tp = wave*64 + j*16 + frow.
+    __syncthreads();                                   // ring / patch / exchange buffers are dead from here on
+    unsigned char* const resT = smem;
+    unsigned char* const outT = smem + 256 * 128;
+    auto pix_off = [&](int tp) -> size_t {
+        if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + (tp >> 6)) * a.out_img + (size_t)((tp >> 3) & 7) * a.out_row + (size_t)(tp & 7) * a.out_pix;
+        else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
+    };
+    constexpr int NTHR = 256 * KS;
+    if (a.res) {
+#pragma unroll
+        for (int it = 0; it < 2048 / NTHR; ++it) {
+            const int idx = tid + it * NTHR, tp = idx >> 3, c = idx & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.res + pix_off(tp) + n_blk + c * 8);
+            *reinterpret_cast<uint4*>(resT + tp * 128 + ((c ^ (tp & 7)) * 16)) = v;
+        }
+        __syncthreads();
+    }
     auto epilogue = [&](auto I0c) {
         constexpr int I0 = decltype(I0c)::value, NI = 4 / KS;
         float psum[NI][4];
@@ -278,22 +337,20 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         for (int i = 0; i < NI; ++i) psum[i][0] = psum[i][1] = psum[i][2] = psum[i][3] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int b, y, x;
-            if constexpr (W8) { b = img0 + wave; y = 2 * j + (frow >> 3); x = frow & 7; }
-            else { b = img0; y = y0 + wave * 4 + j; x = x0 + frow; }
-            const size_t obase = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)y * a.out_row + (size_t)x * a.out_pix;
+            const int tp = wave * 64 + j * 16 + frow;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int n = n_blk + (I0 + i) * 16 + fq * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                const int nl = (I0 + i) * 16 + fq * 4;                 // channel within the 64-channel block
+                const int loff = tp * 128 + ((((I0 + i) * 2 + (fq >> 1)) ^ (tp & 7)) * 16) + (fq & 1) * 8;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n_blk + nl);
                 const f32x4 c = acc[I0 + i][j];
                 float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
                 if (a.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
+                    const uint2 rv = *reinterpret_cast<const uint2*>(resT + loff);
                     v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
                 }
                 if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                *reinterpret_cast<uint2*>(outT + loff) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                 psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
             }
         }
@@ -312,21 +369,46 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
             }
         }
     };
+    CSTAMP(5);
     if constexpr (KS == 1) epilogue(std::integral_constant<int, 0>{});
     else { if (kw == 0) epilogue(std::integral_constant<int, 0>{}); else epilogue(std::integral_constant<int, 2>{}); }
+    if (a.out) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2048 / NTHR; ++it) {
+            const int idx = tid + it * NTHR, tp = idx >> 3, c = idx & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(outT + tp * 128 + ((c ^ (tp & 7)) * 16));
+            *reinterpret_cast<uint4*>(a.out + pix_off(tp) + n_blk + c * 8) = v;
+        }
+    }
+    CSTAMP(6);
 }
 
 template <bool W8, int KS, int NS>
 int launch(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, KS, NS>;
     constexpr size_t lds = (size_t)NS * kWStage + G::PATCH;
-    static_assert(lds >= 8 * 8192, "K-half exchange needs 64 KB");
+    static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
     static bool set = false;
     if (!set) {
         SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         set = true;
     }
+#ifdef SPSP_CONV_STAMPS
+    if (getenv("SPSP_CONV_DEBUG")) {
+        ConvArgs b = a;
+        (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
+        conv3x3_patch_kernel<W8, KS, NS><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(b);
+        (void)hipDeviceSynchronize();
+        unsigned long long h[16];
+        (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "patch<W8=%d,KS=%d,NS=%d> chunks=%d wgs=%d: K loop %llu | K-half exchange + residual staging %llu | epilogue + stores %llu | total %llu cycles\n",
+                (int)W8, KS, NS, a.chunks, (a.M / 256) * (a.N / 64), h[4] - h[0], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        (void)hipFree(b.dbg);
+        return SPSP_OK;
+    }
+#endif
     conv3x3_patch_kernel<W8, KS, NS><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
