@@ -43,6 +43,10 @@ int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 bool conv_patch_supported(const ConvArgs& a);
 int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream);
 
+// conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
+bool conv_wres_supported(const ConvArgs& a);
+int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);
+
 // conv1_patch.hip: the 7x7/2 stem with an LDS-resident 13-row input patch (4 output rows x 128 px x 64 ch per workgroup)
 int launch_conv1_patch(const ConvArgs& a, hipStream_t stream);
 

@@ -205,6 +205,7 @@ struct spsp_regressor {
     int splitk[4];
     bool use_patch;        // 3x3 stride-1 convs through conv_patch.hip
     bool conv1_patch;      // stem through conv1_patch.hip
+    bool use_wres;         // layer1 through conv_wres.hip
     int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs)
 };
 
@@ -234,6 +235,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
     a.relu = relu;
     a.splitk = 1;
+    if (L >= 0 && r->use_wres && conv_wres_supported(a)) {
+        ProfScope ps(ctx, kKConvWres, st);
+        return launch_conv_wres(a, ctx->num_cus, st);
+    }
     if (L >= 0 && r->use_patch && conv_patch_supported(a)) {
         const int v = r->patch_variant[L];
         const int kid3 = a.Wo == 8 ? (v ? kKPatchW8Big : kKPatchW8Small) : (v ? kKPatchW16Big : kKPatchW16Small);
@@ -331,6 +336,8 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->splitk[L] = def_s[L]; }
         r->use_patch = true;
         if (const char* pe = getenv("SPSP_CONV_PATCH")) r->use_patch = atoi(pe) != 0;
+        r->use_wres = true;
+        if (const char* pe = getenv("SPSP_CONV_WRES")) r->use_wres = atoi(pe) != 0;
         r->conv1_patch = true;
         if (const char* pe = getenv("SPSP_CONV1_PATCH")) r->conv1_patch = atoi(pe) != 0;
         const int def_v[4] = {1, 1, 1, 1};   // measured: the 8-wave variant wins on every stage at 32 crops
