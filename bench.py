@@ -143,8 +143,46 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides ----
-    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')      # HIP-event pair around every launch
+    def read_profile(nsteps):
+        nk = r.lib.spsp_profile_num_kernels()
+        ms = (C.c_double * nk)()
+        cnt = (C.c_int * nk)()
+        r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'spsp_profile_read')
+        out = {}
+        for i in range(nk):
+            if cnt[i]:
+                out[r.lib.spsp_profile_kernel_name(i).decode()] = {'id': i, 'launches_per_step': cnt[i] / nsteps,
+                                                                   'avg_us': 1e3 * ms[i] / cnt[i],
+                                                                   'us_per_step': 1e3 * ms[i] / nsteps}
+        return out
+
+    # ---- untimed per-kernel pass: every kernel bracketed by a HIP-event pair on its launch stream, ONE batch in
+    # flight (slot 0, a sync after every step), so a launch's duration is free of the cross-batch sharing the
+    # pipelined timed region has by design (and agrees with the rocprofv3 average of the same command)
+    iso_steps = 8
+    r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
+    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
+    for _ in range(iso_steps):
+        pipe._next = 0
+        step()
+        torch.cuda.synchronize()
+    r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
+    kernels_iso = read_profile(iso_steps)
+    pipe._next = 0
+    # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all have the
+    # same shape: the stem (1 launch/step) and the 3x3 stride-1 kernels (every 3x3/1 conv of ResNet-18 has
+    # 150 994 944 MACs per crop, whatever its layer)
+    cands = {'conv1_patch_kernel': FLOP_CONV1 * B, 'conv_igemm_kernel<128, 64, 128, 8>': FLOP_CONV1 * B}
+    for k in kernels_iso:
+        if k.startswith('conv3x3_'):
+            cands[k] = FLOP_L1CONV * B
+    dom = max(cands, key=lambda k: kernels_iso.get(k, {'us_per_step': 0})['us_per_step'])
+
+    # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides.  Only the dominant kernel keeps
+    # its event pair here: a pair is a barrier on its in-order stream, and bracketing all ~60 launches of a step costs
+    # ~15 % throughput (measured), which would make `value` a profile-mode number.
+    r.check(r.lib.spsp_profile_select(r.ctx, kernels_iso[dom]['id']), 'spsp_profile_select')
+    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -154,46 +192,15 @@ def main():
     barrier()
     t1 = time.perf_counter()
     r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
+    r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = elapsed.item()
     assert torch.isfinite(out.vertices).all() and out.vertices.abs().max().item() > 0.1
-
-    def read_profile(nsteps):
-        nk = r.lib.spsp_profile_num_kernels()
-        ms = (C.c_double * nk)()
-        cnt = (C.c_int * nk)()
-        r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'spsp_profile_read')
-        out = {}
-        for i in range(nk):
-            if cnt[i]:
-                out[r.lib.spsp_profile_kernel_name(i).decode()] = {'launches_per_step': cnt[i] / nsteps,
-                                                                   'avg_us': 1e3 * ms[i] / cnt[i],
-                                                                   'us_per_step': 1e3 * ms[i] / nsteps}
-        return out
-
     kernels = read_profile(args.steps)
-    # the same kernels with ONE batch in flight (slot 0 only, a sync after every step): per-launch durations free of
-    # the cross-batch sharing that the pipelined timed region has by design
-    iso_steps = 8
-    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
-    for _ in range(iso_steps):
-        pipe._next = 0
-        step()
-        torch.cuda.synchronize()
-    r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
-    kernels_iso = read_profile(iso_steps)
 
     if rank == 0:
-        # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all have
-        # the same shape: the stem (1 launch/step) and the 3x3 stride-1 patch kernels (every 3x3/1 conv of ResNet-18
-        # has 150 994 944 MACs per crop, whatever its layer)
-        cands = {'conv1_patch_kernel': FLOP_CONV1 * B, 'conv_igemm_kernel<128, 64, 128, 8>': FLOP_CONV1 * B}
-        for k in kernels:
-            if k.startswith('conv3x3_patch_kernel'):
-                cands[k] = FLOP_L1CONV * B
-        dom = max(cands, key=lambda k: kernels.get(k, {'us_per_step': 0})['us_per_step'])
         achieved = cands[dom] / (kernels[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels else None
         achieved_iso = cands[dom] / (kernels_iso[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels_iso else None
         conv_us = sum(v['us_per_step'] for k, v in kernels_iso.items() if k.startswith('conv'))
@@ -213,8 +220,9 @@ def main():
                        'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
-            # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region an event pair also
-            # spans the time a launch queues behind other batches' kernels; that figure is kept as *_timed_region.
+            # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's
+            # event pair also spans the time its workgroups share CUs with other batches' kernels; that figure is
+            # kept as *_timed_region.
             'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved_iso, 'peak': MFMA_BF16_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': (achieved_iso / MFMA_BF16_PEAK_TFLOPS) if achieved_iso else None,
                          'traffic': traffic,
@@ -224,7 +232,7 @@ def main():
                          'achieved_timed_region': achieved,
                          'all_convs_tflops': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12) if conv_us else None,
                          'end_to_end_backbone_tflops': FLOP_BACKBONE * B * args.steps / elapsed / 1e12},
-            'kernels_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels.items()},
+            'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -62,8 +62,11 @@ const char* spsp_version(void);
 /* ---- per-kernel timing (bench.py roofline leg): while enabled, every launch site records a HIP-event
  *      pair on the launch stream; spsp_profile_read synchronises them, sums milliseconds and launch counts
  *      per kernel id (a scope that issues several launches of one kernel counts as one record per launch
- *      site) and clears the records. */
+ *      site) and clears the records.  An event pair is a barrier on its in-order stream (no back-to-back
+ *      dispatch across it), so spsp_profile_select(kernel_id) restricts recording to one kernel id
+ *      (-1 = all) for use inside a throughput-timed region. */
 int         spsp_profile_enable(spsp_ctx* ctx, int on);
+int         spsp_profile_select(spsp_ctx* ctx, int kernel_id);
 int         spsp_profile_num_kernels(void);
 const char* spsp_profile_kernel_name(int id);
 int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);

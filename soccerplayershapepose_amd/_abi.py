@@ -86,6 +86,7 @@ _PROTOS = {
     'spsp_last_error': (C.c_char_p, []),
     'spsp_version': (C.c_char_p, []),
     'spsp_profile_enable': (C.c_int, [_vp, C.c_int]),
+    'spsp_profile_select': (C.c_int, [_vp, C.c_int]),
     'spsp_profile_num_kernels': (C.c_int, []),
     'spsp_profile_kernel_name': (C.c_char_p, [C.c_int]),
     'spsp_profile_read': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

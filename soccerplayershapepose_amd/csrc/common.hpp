@@ -90,6 +90,7 @@ struct spsp_ctx {
     int device;
     int num_cus;
     bool prof_on = false;
+    int prof_only = -1;                 // >= 0: record only this kernel id (spsp_profile_select)
     std::vector<spsp::ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_free;
 };
@@ -99,7 +100,7 @@ namespace spsp {
 struct ProfScope {
     spsp_ctx* ctx; hipStream_t st; hipEvent_t stop = nullptr;
     ProfScope(spsp_ctx* c, int id, hipStream_t s) : ctx(c), st(s) {
-        if (!c || !c->prof_on) return;
+        if (!c || !c->prof_on || (c->prof_only >= 0 && c->prof_only != id)) return;
         hipEvent_t ev[2];
         for (auto& e : ev) {
             if (!c->prof_free.empty()) { e = c->prof_free.back(); c->prof_free.pop_back(); }

@@ -55,6 +55,12 @@ int spsp_profile_enable(spsp_ctx* ctx, int on) {
     return SPSP_OK;
 }
 
+int spsp_profile_select(spsp_ctx* ctx, int kernel_id) {
+    SPSP_REQUIRE(ctx && kernel_id >= -1 && kernel_id < spsp::kKNumKernels, "spsp_profile_select: kernel id out of range");
+    ctx->prof_only = kernel_id;
+    return SPSP_OK;
+}
+
 int spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches) {
     SPSP_REQUIRE(ctx && total_ms && launches && n >= spsp::kKNumKernels, "spsp_profile_read: need %d slots", spsp::kKNumKernels);
     for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
