@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth', type=int, default=4, help='pipeline slots (HIP streams); 1 = strictly serial steps')
+    ap.add_argument('--graphs', action='store_true', help='replay each slot\'s step from a captured HIP graph (no in-region kernel events)')
     ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
     return ap.parse_args()
@@ -181,8 +182,15 @@ def main():
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides.  Only the dominant kernel keeps
     # its event pair here: a pair is a barrier on its in-order stream, and bracketing all ~60 launches of a step costs
     # ~15 % throughput (measured), which would make `value` a profile-mode number.
-    r.check(r.lib.spsp_profile_select(r.ctx, kernels_iso[dom]['id']), 'spsp_profile_select')
-    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
+    if args.graphs:
+        # each slot's step is captured into a HIP graph (untimed) and replayed; events are not recorded inside graphs
+        pipe.use_graphs = True
+        for _ in range(len(pipe.slots)):
+            step()
+        torch.cuda.synchronize()
+    else:
+        r.check(r.lib.spsp_profile_select(r.ctx, kernels_iso[dom]['id']), 'spsp_profile_select')
+        r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -218,7 +226,7 @@ def main():
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,264,18] resident in HBM',
-                       'pipeline_slots': max(1, args.depth)},
+                       'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
             # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's
             # event pair also spans the time its workgroups share CUs with other batches' kernels; that figure is

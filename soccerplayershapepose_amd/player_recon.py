@@ -140,25 +140,59 @@ class PlayerPipeline:
     underneath the MFMA-bound backbone of batch i+1.  Every batch still goes through the complete path; results
     are returned with the event that marks their completion."""
 
-    def __init__(self, make_regressor, make_smpl, device, depth=2):
+    def __init__(self, make_regressor, make_smpl, device, depth=2, use_graphs=False):
         self.device = torch.device(device)
+        self.use_graphs = bool(use_graphs)
         self.slots = []
         for _ in range(depth):
             st = torch.cuda.Stream(device=self.device)
             self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
-                                              smpl=make_smpl().to(self.device), done=None))
+                                              smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False))
         self._next = 0
 
     def submit(self, proxy_rep, joints2D, **kw):
+        """Issue one batch on the next slot.  With `use_graphs` the slot's ~60 launches are captured once into a
+        HIP graph (keyed by the input buffers and options) and replayed: ~20 us of host time per batch instead of
+        ~180 us, bit-identical results; the returned tensors are then the graph's static outputs, valid until
+        the same slot is submitted to again (depth submits later)."""
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         slot.stream.wait_stream(torch.cuda.current_stream(self.device))     # inputs produced on the caller's stream
+        if self.use_graphs:
+            return self._submit_graph(slot, proxy_rep, joints2D, kw)
         with torch.cuda.stream(slot.stream):
             res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
             res.done = torch.cuda.Event()
             res.done.record(slot.stream)
         res.stream = slot.stream
         return res
+
+    def _submit_graph(self, slot, proxy_rep, joints2D, kw):
+        if not (torch.is_tensor(proxy_rep) and proxy_rep.is_cuda and torch.is_tensor(joints2D) and joints2D.is_cuda):
+            raise ValueError('PlayerPipeline(use_graphs=True): inputs must be device tensors (a graph replays fixed buffers)')
+        key = (proxy_rep.data_ptr(), tuple(proxy_rep.shape), proxy_rep.dtype, joints2D.data_ptr(), tuple(joints2D.shape),
+               joints2D.dtype, tuple(sorted(kw.items())))
+        with torch.cuda.stream(slot.stream):
+            entry = slot.graphs.get(key)
+            if entry is None:
+                if not slot.warm:       # first use of the slot: run eagerly once (one-time kernel attribute set-up)
+                    reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
+                    slot.warm = True
+                slot.stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=slot.stream):
+                    res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
+                if len(slot.graphs) >= 8:
+                    slot.graphs.pop(next(iter(slot.graphs)))
+                # the inputs are kept alive with the graph that reads them
+                entry = slot.graphs[key] = (g, res, proxy_rep, joints2D)
+            g, res = entry[0], entry[1]
+            g.replay()
+            out = SimpleNamespace(**vars(res))
+            out.done = torch.cuda.Event()
+            out.done.record(slot.stream)
+        out.stream = slot.stream
+        return out
 
     def synchronize(self):
         for s in self.slots:

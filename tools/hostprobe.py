@@ -25,3 +25,29 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f'B={B} depth={depth}: host enqueue {1e6*(t1-t0)/K:.0f} us/step, total {1e6*(t2-t0)/K:.0f} us/step -> {B*K/(t2-t0):.0f} players/s')
+
+# ---- same steps replayed from a HIP graph per slot ----
+if len(sys.argv) > 3 and sys.argv[3] == 'graph':
+    from soccerplayershapepose_amd.player_recon import reconstruct_players
+    graphs = []
+    for slot in pipe.slots:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=slot.stream):
+            res = reconstruct_players(slot.regressor, slot.smpl, native, tgt, fit='pose_shape', iters=50)
+        graphs.append((g, res, slot.stream))
+    torch.cuda.synchronize()
+    def replay(i):
+        g, res, st = graphs[i % depth]
+        with torch.cuda.stream(st):
+            g.replay()
+    for i in range(8): replay(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K): replay(i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f'GRAPH B={B} depth={depth}: host enqueue {1e6*(t1-t0)/K:.0f} us/step, total {1e6*(t2-t0)/K:.0f} us/step -> {B*K/(t2-t0):.0f} players/s')
+    ref = pipe.submit(native, tgt, fit='pose_shape', iters=50)
+    torch.cuda.synchronize()
+    print('graph vs eager max |dv|:', (ref.vertices - graphs[0][1].vertices).abs().max().item())

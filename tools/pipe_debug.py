@@ -1,0 +1,38 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from soccerplayershapepose_amd import synthetic as S
+from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+from soccerplayershapepose_amd.models.smpl_official import SMPL
+from soccerplayershapepose_amd.player_recon import PlayerPipeline, reconstruct_players
+dev = torch.device('cuda', 0)
+B = 8
+sd = S.regressor_state_dict(seed=0); model = S.smpl_model(seed=0)
+mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B).load_state_dict(sd)
+mk_s = lambda: SMPL(model, max_batch=B)
+x, _ = S.proxy_crops(2 * B, seed=5)
+xa, xb = torch.from_numpy(x[:B]).to(dev), torch.from_numpy(x[B:]).to(dev)
+tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(3)) * 300 + 100).to(dev)
+ref_reg, ref_smpl = mk_r().to(dev), mk_s().to(dev)
+na, nb = ref_reg.pack(xa).clone(), ref_reg.pack(xb).clone()
+def run(n):
+    r = reconstruct_players(ref_reg, ref_smpl, n, tgt, fit='pose_shape', iters=10)
+    return {k: getattr(r, k).clone() for k in ('cam', 'rotmats', 'betas', 'vertices')}
+a1 = run(na); b1 = run(nb); a2 = run(na); b2 = run(nb)
+for k in a1: print('serial repeat', k, (a1[k]-a2[k]).abs().max().item(), (b1[k]-b2[k]).abs().max().item())
+# regressor only
+def regonly(n):
+    c, p, s = ref_reg(n); return torch.cat([c, p, s], 1).clone()
+ra, rb, ra2, rb2 = regonly(na), regonly(nb), regonly(na), regonly(nb)
+print('regressor repeat', (ra-ra2).abs().max().item(), (rb-rb2).abs().max().item())
+for g in (False, True):
+    pipe = PlayerPipeline(mk_r, mk_s, dev, depth=3, use_graphs=g)
+    buf = na.clone()
+    outs = [pipe.submit(buf, tgt, fit='pose_shape', iters=10) for _ in range(3)]
+    pipe.synchronize()
+    print('graphs', g, 'phase a', [(o.vertices - a1['vertices']).abs().max().item() for o in outs])
+    buf.copy_(nb); torch.cuda.synchronize()
+    outs = [pipe.submit(buf, tgt, fit='pose_shape', iters=10) for _ in range(4)]
+    pipe.synchronize()
+    print('graphs', g, 'phase b', [(o.vertices - b1['vertices']).abs().max().item() for o in outs],
+          [(o.cam - b1['cam']).abs().max().item() for o in outs])
