@@ -1,6 +1,6 @@
 // GPU driver of the reprojection fit: one 256-thread workgroup (4 wavefronts) per player, all iterations in one
 // launch, state in LDS (~29 KB), Adam moments in registers (one parameter per lane).  The arithmetic lives in fit_core.hpp (shared with the
-// host emulation used by the CPU tests).  Latency-bound by design (~27 single-wave barriers / iteration);
+// host emulation used by the CPU tests).  Latency-bound by design (10 workgroup barriers / iteration);
 // players are independent, so a batch fills one CU per player.
 #include <cmath>
 #include <cstdlib>
