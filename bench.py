@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth', type=int, default=4, help='pipeline slots (HIP streams); 1 = strictly serial steps')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16'], help='backbone storage / MFMA element type')
     ap.add_argument('--graphs', action='store_true', help='replay each slot\'s step from a captured HIP graph (no in-region kernel events)')
     ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
@@ -102,7 +103,7 @@ def main():
     sd = S.regressor_state_dict(seed=0)
     model = S.smpl_model(seed=0)
     def make_regressor():
-        m = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B)
+        m = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=args.precision)
         return m.load_state_dict(sd)
 
     def make_smpl():
@@ -220,12 +221,12 @@ def main():
             'metric': 'players/sec end-to-end (backbone+SMPL+fit) on 256x256 crops',
             'value': world * B * args.steps / elapsed, 'unit': 'players/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'batch-{B} 256x256 synthetic proxy crops per GPU: ResNet-18+IEF regressor (bf16 MFMA, '
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': f'batch-{B} 256x256 synthetic proxy crops per GPU: ResNet-18+IEF regressor ({args.precision} MFMA, '
                                    f'fp32 accumulate) -> rot6d -> {FIT_ITERS}-iter {args.fit} Adam fit -> SMPL forward '
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
-                       'parallelism': f'dp{world}', 'input_layout': 'NHWC bf16 [262,264,18] resident in HBM',
+                       'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
             # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's

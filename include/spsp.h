@@ -93,19 +93,23 @@ const char* spsp_conv_name(int i);
 /* State-dict prefix of the BatchNorm that follows conv i. */
 const char* spsp_conv_bn_name(int i);
 
-/* precision: 0 = bf16 MFMA (bf16 weights/activations, fp32 accumulate);
- *            1 = split-bf16 x3 MFMA (hi+lo planes, ~fp32-accurate; 3x the MFMA work). */
+/* precision: 0 = bf16 weights/activations on v_mfma_f32_16x16x32_bf16, fp32 accumulate (the default);
+ *            1 = fp16 weights/activations on v_mfma_f32_16x16x32_f16, fp32 accumulate: same layouts, bytes and
+ *                speed, 3 more mantissa bits (activations are O(1..10), well inside fp16 range) -- the mode in
+ *                which the END-TO-END vertices stay within 1e-3 m of the all-fp32 reference path. */
+#define SPSP_PRECISION_BF16 0
+#define SPSP_PRECISION_F16  1
 int  spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_batch, int precision,
                          spsp_regressor** out);
 void spsp_regressor_free(spsp_regressor* r);
 
 #define SPSP_PROXY_NCHW_F32   0  /* [B,18,256,256] fp32 -- what the reference feeds (predict_3D.py:126) */
-#define SPSP_PROXY_NATIVE     1  /* [B,262,264,18] bf16 NHWC, pixel (y,x) at [y+3][x+3], everything else ZERO (caller keeps it so) */
+#define SPSP_PROXY_NATIVE     1  /* [B,262,264,18] NHWC in the handle's element type (bf16 / fp16), pixel (y,x) at [y+3][x+3], everything else ZERO (caller keeps it so) */
 
 /* Bytes of one crop in the native layout. */
 size_t spsp_proxy_native_bytes(void);
-/* NCHW fp32 -> native layout (writes interior AND border). */
-int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_out, void* stream);
+/* NCHW fp32 -> native layout in the element type of `precision` (writes interior AND border). */
+int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, int precision, void* native_out, void* stream);
 
 /* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,

@@ -26,6 +26,17 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def _f16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+def _quantiser(emulate):
+    """emulate: False/None = fp32; True or 'bf16' = the HIP backbone's default storage type; 'f16' = its precision-1 mode."""
+    if not emulate:
+        return None
+    return _f16 if emulate == 'f16' else _bf16
+
+
 def fold_bn(sd, conv, bn):
     """Eval-mode BN folded into the preceding bias-free conv: returns (w', b') fp32."""
     w = _t(sd[conv + '.weight']).double()
@@ -36,9 +47,10 @@ def fold_bn(sd, conv, bn):
 
 
 def _conv_bn(sd, x, conv, bn, stride, pad, emulate_bf16):
-    if emulate_bf16:
+    qz = _quantiser(emulate_bf16)
+    if qz is not None:
         w, b = fold_bn(sd, conv, bn)
-        return F.conv2d(x, _bf16(w), b, stride=stride, padding=pad)
+        return F.conv2d(x, qz(w), b, stride=stride, padding=pad)
     y = F.conv2d(x, _t(sd[conv + '.weight']), None, stride=stride, padding=pad)
     return F.batch_norm(y, _t(sd[bn + '.running_mean']), _t(sd[bn + '.running_var']),
                         _t(sd[bn + '.weight']), _t(sd[bn + '.bias']), False, 0.0, BN_EPS)
@@ -46,7 +58,7 @@ def _conv_bn(sd, x, conv, bn, stride, pad, emulate_bf16):
 
 def encoder_forward(sd, x, emulate_bf16=False, return_stages=False):
     """[B,18,256,256] -> [B,512] pooled features (`PR/models/resnet.py:201-216`)."""
-    q = _bf16 if emulate_bf16 else (lambda t: t)
+    q = _quantiser(emulate_bf16) or (lambda t: t)
     stages = {}
     x = q(_t(x).float())
     p = 'image_encoder.'

@@ -61,6 +61,13 @@ inline uint16_t f32_to_bf16_host(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+// float -> fp16 bits, round-to-nearest-even (host side)
+inline uint16_t f32_to_f16_host(float f) {
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
 inline float bf16_to_f32_host(uint16_t h) {
     uint32_t u = (uint32_t)h << 16;
     float f;

@@ -12,6 +12,7 @@
 // (chunk ^ (row & (BK/8-1))): a ds_read_b128 fragment read (16 rows x 4 k-chunks per 16-lane group) then
 // touches 16 distinct 16-byte slots of the 256-byte bank row -> conflict-free (guide: LDS, T2).
 #include "conv.hpp"
+#include "conv_elem.hpp"
 
 namespace {
 using namespace spsp;
@@ -21,15 +22,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 
 // BM x BN output tile (pixels x channels), BK-deep K-steps, LOADB bytes per lane per activation load.
-template <int BM, int BN, int BK, int LOADB>
+template <int BM, int BN, int BK, int LOADB, bool F16>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int kThreads = 256;
     constexpr int CH16 = BK / 8;                  // 16-byte chunks per LDS row
@@ -159,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = Elem<F16>::mfma(wf[i], xf[j], acc[i][j]);
         }
         if (step + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();
@@ -183,11 +178,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
             if (a.res) {
                 const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
-                v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
             }
             if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             if (valid) {
-                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
                 psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
             }
         }
@@ -213,22 +208,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <int BM, int BN, int BK, int LOADB>
-int launch(const ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int BK, int LOADB, bool F16>
+int launch_t(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(a.N % BN == 0, "conv: N=%d not a multiple of the %d-channel tile", a.N, BN);
     SPSP_REQUIRE(a.M % BM == 0, "conv: M=%d not a multiple of the %d-pixel tile", a.M, BM);
     SPSP_REQUIRE(!a.pool_out || BM == a.Ho * a.Wo, "conv: fused avg-pool needs one image per M tile");
     constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, LOADB>),
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, LOADB, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((a.M / BM) * (a.N / BN));
-    conv_igemm_kernel<BM, BN, BK, LOADB><<<grid, 256, lds, st>>>(a);
+    conv_igemm_kernel<BM, BN, BK, LOADB, F16><<<grid, 256, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
+}
+
+template <int BM, int BN, int BK, int LOADB>
+int launch(const ConvArgs& a, hipStream_t st) {
+    return a.f16 ? launch_t<BM, BN, BK, LOADB, true>(a, st) : launch_t<BM, BN, BK, LOADB, false>(a, st);
 }
 
 }  // namespace

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "conv.hpp"
+#include "conv_elem.hpp"
 
 namespace {
 using namespace spsp;
@@ -24,10 +25,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
     bf16x8 v;
@@ -56,6 +53,7 @@ constexpr int kPatchB = kPatchPieces * 1024;
 constexpr int kWStage = 64 * 256;                   // [64 n][128 k] bf16
 constexpr int kLds = kPatchB + 2 * kWStage;
 
+template <bool F16>
 __global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const ring = smem + kPatchB;
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = Elem<F16>::mfma(wf[kk][i], xf[kk][j], acc[i][j]);
         }
     }
 
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
             float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
             if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             *reinterpret_cast<uint2*>(outT + tp * 128 + (((i * 2 + (fq >> 1)) ^ (tp & 7)) * 16) + (fq & 1) * 8) =
-                make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
         }
     }
     __syncthreads();
@@ -183,12 +181,15 @@ int launch_conv1_patch(const ConvArgs& a, hipStream_t st) {
                  "conv1_patch: geometry is fixed to the 7x7/2 stem on the [262,264,18] native layout");
     static bool set = false;
     if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_patch_kernel),
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_patch_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_patch_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
         set = true;
     }
     const int B = a.M / (128 * 128);
-    conv1_patch_kernel<<<dim3(B * 32), 512, kLds, st>>>(a);
+    if (a.f16) conv1_patch_kernel<true><<<dim3(B * 32), 512, kLds, st>>>(a);
+    else conv1_patch_kernel<false><<<dim3(B * 32), 512, kLds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "conv.hpp"
+#include "conv_elem.hpp"
 
 namespace {
 using namespace spsp;
@@ -38,12 +39,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
@@ -78,7 +73,7 @@ struct Geo {
 };
 
 // One workgroup: 256 pixels x 64 channels.  grid = (M/256) * (N/64) (XCD-contiguous order).
-template <bool W8, int KS, int NS>
+template <bool W8, int KS, int NS, bool F16>
 __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs a) {
     using G = Geo<W8, KS, NS>;
     constexpr int PW = G::PW, kNS = NS, NW = G::NW;
@@ -212,7 +207,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         _Pragma("unroll") for (int kk = 0; kk < NK; ++kk)                                                 \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = Elem<F16>::mfma(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j]); \
     }
     // wait until weight stage s has landed: `ahead` younger stages (LPS pieces each) may stay in flight
     auto wait_stage = [&](int ahead) {
@@ -347,10 +342,10 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
                 float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
                 if (a.res) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(resT + loff);
-                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                    v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
                 }
                 if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                *reinterpret_cast<uint2*>(outT + loff) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                *reinterpret_cast<uint2*>(outT + loff) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
                 psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
             }
         }
@@ -384,14 +379,14 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     CSTAMP(6);
 }
 
-template <bool W8, int KS, int NS>
-int launch(const ConvArgs& a, hipStream_t st) {
+template <bool W8, int KS, int NS, bool F16>
+int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, KS, NS>;
     constexpr size_t lds = (size_t)NS * kWStage + G::PATCH;
     static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
     static bool set = false;
     if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS>),
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         set = true;
     }
@@ -399,7 +394,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
         (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_patch_kernel<W8, KS, NS><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(b);
+        conv3x3_patch_kernel<W8, KS, NS, F16><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(b);
         (void)hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
@@ -409,9 +404,14 @@ int launch(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    conv3x3_patch_kernel<W8, KS, NS><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(a);
+    conv3x3_patch_kernel<W8, KS, NS, F16><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
+}
+
+template <bool W8, int KS, int NS>
+int launch(const ConvArgs& a, hipStream_t st) {
+    return a.f16 ? launch_t<W8, KS, NS, true>(a, st) : launch_t<W8, KS, NS, false>(a, st);
 }
 
 }  // namespace

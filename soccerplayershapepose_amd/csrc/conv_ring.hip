@@ -13,6 +13,7 @@
 // wave-instruction writes 8 rows x 128 B), so the swizzle is applied to the per-lane SOURCE address and again on
 // the fragment read (guide rule 21: both sides or neither).
 #include "conv.hpp"
+#include "conv_elem.hpp"
 
 namespace {
 using namespace spsp;
@@ -22,12 +23,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
@@ -44,7 +39,7 @@ __device__ __forceinline__ void dma16(const uint16_t* gsrc, unsigned char* lds_w
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NS, bool SPLITK>
+template <int BM, int BN, int NS, bool SPLITK, bool F16>
 __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     constexpr int BK = 64, ROWB = 128;
     constexpr int STAGE = (BM + BN) * ROWB;
@@ -153,14 +148,14 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = Elem<F16>::mfma(wf[0][i], xf[0][j], acc[i][j]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = Elem<F16>::mfma(wf[1][i], xf[1][j], acc[i][j]);
     }
 
     // ---- epilogue ----
@@ -193,10 +188,10 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
                 float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
                 if (a.res) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
-                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                    v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
                 }
                 if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
                 psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
             }
         }
@@ -222,6 +217,7 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
 
 // Split-K second pass: out = act(sum_s slab[s] + bias (+ residual)) as bf16 NHWC (+ fused global avg-pool).
 // One thread per (pixel, 4 channels); for the pooled layer a workgroup covers whole images.
+template <bool F16>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) {
     const int n4 = a.N / 4;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -241,10 +237,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) 
     const size_t obase = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)ho * a.out_row + (size_t)wo * a.out_pix;
     if (a.res) {
         const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
-        v.x += bf16_lo(rv.x); v.y += bf16_hi(rv.x); v.z += bf16_lo(rv.y); v.w += bf16_hi(rv.y);
+        v.x += Elem<F16>::lo(rv.x); v.y += Elem<F16>::hi(rv.x); v.z += Elem<F16>::lo(rv.y); v.w += Elem<F16>::hi(rv.y);
     }
     if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(Elem<F16>::pack2(v.x, v.y), Elem<F16>::pack2(v.z, v.w));
     if (a.pool_out) {
         // fp32 values kept for the pool pass in slab 0 (overwrites this thread's own input element only)
         *reinterpret_cast<float4*>(a.part + (size_t)m * a.N + n) = v;
@@ -261,8 +257,8 @@ __global__ void pool_from_slab_kernel(const float* __restrict__ slab, int HoWo, 
     }
 }
 
-template <int BM, int BN, int NS>
-int launch(const ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int NS, bool F16>
+int launch_t(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(a.N % BN == 0 && a.M % BM == 0, "conv_ring: M=%d N=%d not multiples of the %dx%d tile", a.M, a.N, BM, BN);
     SPSP_REQUIRE(a.in_pix % 8 == 0 && a.in_off % 8 == 0 && a.in_row % 8 == 0, "conv_ring: input not 16-byte aligned");
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
@@ -271,14 +267,14 @@ int launch(const ConvArgs& a, hipStream_t st) {
         SPSP_REQUIRE(a.part != nullptr, "conv_ring: split-K needs a slab workspace");
         static bool set = false;
         if (!set) {
-            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, NS, true>),
+            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, NS, true, F16>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             set = true;
         }
-        conv_ring_kernel<BM, BN, NS, true><<<dim3(tiles, a.splitk), 256, lds, st>>>(a);
+        conv_ring_kernel<BM, BN, NS, true, F16><<<dim3(tiles, a.splitk), 256, lds, st>>>(a);
         SPSP_HIP_CHECK(hipGetLastError());
         const size_t total = (size_t)a.M * (a.N / 4);
-        splitk_epilogue_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+        splitk_epilogue_kernel<F16><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
         SPSP_HIP_CHECK(hipGetLastError());
         if (a.pool_out) {
             pool_from_slab_kernel<<<a.M / (a.Ho * a.Wo), 256, 0, st>>>(a.part, a.Ho * a.Wo, a.N, a.pool_out);
@@ -289,13 +285,18 @@ int launch(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(!a.pool_out || BM == a.Ho * a.Wo, "conv_ring: fused avg-pool needs one image per M tile");
     static bool set = false;
     if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, NS, false>),
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, NS, false, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         set = true;
     }
-    conv_ring_kernel<BM, BN, NS, false><<<dim3(tiles, 1), 256, lds, st>>>(a);
+    conv_ring_kernel<BM, BN, NS, false, F16><<<dim3(tiles, 1), 256, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
+}
+
+template <int BM, int BN, int NS>
+int launch(const ConvArgs& a, hipStream_t st) {
+    return a.f16 ? launch_t<BM, BN, NS, true>(a, st) : launch_t<BM, BN, NS, false>(a, st);
 }
 
 }  // namespace

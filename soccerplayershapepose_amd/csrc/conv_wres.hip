@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "conv.hpp"
+#include "conv_elem.hpp"
 
 namespace {
 using namespace spsp;
@@ -23,12 +24,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    f32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
     bf16x8 v;
@@ -53,6 +48,7 @@ constexpr int kLds = kWAll + kPatch + kStage;    // 148 480 B
 #define WSTAMP(i)
 #endif
 
+template <bool F16>
 __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const wlds = smem;
@@ -176,7 +172,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                       \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = Elem<F16>::mfma(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j]); \
     }
 #define WRES_STEP(TAP, SET)                                                                    \
     {                                                                                          \
@@ -224,10 +220,10 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
                 float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
                 if (has_res) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(stage + loff);      // own slot: read, then overwrite
-                    v0 += bf16_lo(rv.x); v1 += bf16_hi(rv.x); v2 += bf16_lo(rv.y); v3 += bf16_hi(rv.y);
+                    v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
                 }
                 if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                *reinterpret_cast<uint2*>(stage + loff) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                *reinterpret_cast<uint2*>(stage + loff) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
             }
         }
         __syncthreads();
@@ -255,7 +251,9 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
     SPSP_REQUIRE(conv_wres_supported(a), "conv_wres: needs a 3x3 stride-1 64->64 convolution on a map that is a multiple of 16 wide");
     static bool set = false;
     if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wres_kernel),
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wres_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wres_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
         set = true;
     }
@@ -265,7 +263,7 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
         (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_wres_kernel<<<dim3(grid), 256, kLds, st>>>(b);
+        conv3x3_wres_kernel<false><<<dim3(grid), 256, kLds, st>>>(b);
         (void)hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
@@ -275,7 +273,8 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    conv3x3_wres_kernel<<<dim3(grid), 256, kLds, st>>>(a);
+    if (a.f16) conv3x3_wres_kernel<true><<<dim3(grid), 256, kLds, st>>>(a);
+    else conv3x3_wres_kernel<false><<<dim3(grid), 256, kLds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "conv.hpp"
+#include "conv_elem.hpp"
 
 namespace {
 using namespace spsp;
@@ -40,7 +41,8 @@ const ConvDesc kConvs[SPSP_NUM_CONVS] = {
 };
 
 // ---- layout kernels -------------------------------------------------------------------------------------
-// NCHW fp32 [B,18,256,256] -> native [B,262,264,18] bf16 (interior + zero border).
+// NCHW fp32 [B,18,256,256] -> native [B,262,264,18] bf16 / fp16 (interior + zero border).
+template <bool F16>
 __global__ void proxy_pack_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst) {
     const int xp = blockIdx.x * blockDim.x + threadIdx.x, yp = blockIdx.y, b = blockIdx.z;
     if (xp >= kWWp) return;
@@ -52,10 +54,7 @@ __global__ void proxy_pack_kernel(const float* __restrict__ src, uint16_t* __res
     for (int c = 0; c < kCin; c += 2) {
         float v0 = 0.f, v1 = 0.f;
         if (inside) { v0 = s[(size_t)c * kWH * kWH]; v1 = s[(size_t)(c + 1) * kWH * kWH]; }
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        f32x2 v = {v0, v1};
-        d[c / 2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        d[c / 2] = Elem<F16>::pack2(v0, v1);
     }
 }
 
@@ -72,27 +71,24 @@ __global__ void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __rest
     const int ho = t % Ho;
     const int b = (int)(t / Ho);
     const int Wi = 2 * Wo + 2, Hi = 2 * Ho + 2;
-    float m[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = 0.f;
+    // post-ReLU values are >= +0, and for non-negative bf16 / fp16 alike the numeric order is the order of the
+    // 16-bit patterns: an integer max per half-word, no conversion, the same code for both element types
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
             const uint4 v = *reinterpret_cast<const uint4*>(in + (((size_t)b * Hi + 2 * ho + r) * Wi + 2 * wo + c) * C + g * 8);
             const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                m[2 * i] = fmaxf(m[2 * i], __builtin_bit_cast(float, u[i] << 16));
-                m[2 * i + 1] = fmaxf(m[2 * i + 1], __builtin_bit_cast(float, u[i] & 0xFFFF0000u));
+                const uint32_t lo = max(o[i] & 0xFFFFu, u[i] & 0xFFFFu), hi = max(o[i] >> 16, u[i] >> 16);
+                o[i] = lo | (hi << 16);
             }
         }
-    uint32_t o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)   // values are exact bf16 already: truncation == rounding
-        o[i] = (__builtin_bit_cast(uint32_t, m[2 * i]) >> 16) | (__builtin_bit_cast(uint32_t, m[2 * i + 1]) & 0xFFFF0000u);
     *reinterpret_cast<uint4*>(out + (((size_t)b * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * C + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // padded NHWC bf16 -> NCHW fp32 (parity tap)
+template <bool F16>
 __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int pad) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * C * H * W;
@@ -103,7 +99,7 @@ __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __rest
     const int c = t % C;
     const int b = (int)(t / C);
     const uint16_t v = in[(((size_t)b * (H + 2 * pad) + y + pad) * (W + 2 * pad) + x + pad) * C + c];
-    out[idx] = __builtin_bit_cast(float, (uint32_t)v << 16);
+    out[idx] = Elem<F16>::one(v);
 }
 
 // ---- IEF fully-connected layer (fp32): out[b][n] = act(bias[n] + sum_k x[b][k] W[n][k]) (+ out, if accumulate)
@@ -185,6 +181,7 @@ struct spsp_regressor {
     spsp::DevicePool pool;
     int max_batch;
     int ief_iters;
+    int f16;               // 0: bf16 storage + bf16 MFMA (precision 0), 1: fp16 storage + f16 MFMA (precision 1)
     uint16_t* w[SPSP_NUM_CONVS];
     float* bias[SPSP_NUM_CONVS];
     float* fcw[3];
@@ -221,6 +218,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     ConvArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = in; a.w = r->w[ci]; a.bias = r->bias[ci]; a.res = res; a.out = out; a.pool_out = pool_out;
+    a.f16 = r->f16;
     const int Wi = Si + 2 * bi;
     a.in_pix = d.cin; a.in_row = Wi * d.cin; a.in_img = Wi * Wi * d.cin;
     if (ci == 0) { a.in_row = kWWp * d.cin; a.in_img = kWHp * kWWp * d.cin; }     // native input: 262 rows x 264 columns
@@ -278,7 +276,7 @@ size_t spsp_proxy_native_bytes(void) { return kNativeElems * 2; }
 int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_batch, int precision,
                         spsp_regressor** out) {
     SPSP_REQUIRE(ctx && w && out && max_batch > 0, "spsp_regressor_load: bad arguments");
-    SPSP_REQUIRE(precision == 0, "spsp_regressor_load: precision %d not available in this build (0 = bf16 MFMA)", precision);
+    SPSP_REQUIRE(precision == 0 || precision == 1, "spsp_regressor_load: precision %d (0 = bf16 MFMA, 1 = fp16 MFMA)", precision);
     SPSP_REQUIRE(w->ief_iters >= 0 && w->ief_iters <= 16, "spsp_regressor_load: ief_iters=%d", w->ief_iters);
     for (int i = 0; i < SPSP_NUM_CONVS; ++i)
         SPSP_REQUIRE(w->conv[i].weight && w->conv[i].bn_weight && w->conv[i].bn_bias && w->conv[i].bn_mean && w->conv[i].bn_var,
@@ -289,6 +287,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     spsp_regressor* r = new spsp_regressor;
     r->max_batch = max_batch;
     r->ief_iters = w->ief_iters;
+    r->f16 = precision;
     r->last_B = 0;
     int rc = SPSP_OK;
 #define TRY(x) do { rc = (x); if (rc != SPSP_OK) { delete r; return rc; } } while (0)
@@ -308,7 +307,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
                         const float wv = (float)((double)c.weight[(((size_t)n * d.cin + cin) * d.k + kr) * d.k + kc] * s);
                         const size_t kidx = ci == 0 ? (size_t)kr * 128 + kc * d.cin + cin
                                                     : ((size_t)kr * d.k + kc) * d.cin + cin;
-                        wt[(size_t)n * ktot + kidx] = f32_to_bf16_host(wv);
+                        wt[(size_t)n * ktot + kidx] = precision ? f32_to_f16_host(wv) : f32_to_bf16_host(wv);
                     }
         }
         TRY(r->pool.upload(&r->w[ci], wt.data(), wt.size()));
@@ -372,12 +371,14 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
 
 void spsp_regressor_free(spsp_regressor* r) { delete r; }
 
-int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, void* native_out, void* stream) {
+int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, int precision, void* native_out, void* stream) {
     SPSP_REQUIRE(ctx && proxy_nchw && native_out && B >= 0, "spsp_proxy_pack: bad arguments");
+    SPSP_REQUIRE(precision == 0 || precision == 1, "spsp_proxy_pack: precision %d (0 = bf16, 1 = fp16)", precision);
     if (B == 0) return SPSP_OK;
     dim3 grid((kWWp + 63) / 64, kWHp, B);
     ProfScope ps(ctx, kKProxyPack, as_stream(stream));
-    proxy_pack_kernel<<<grid, 64, 0, as_stream(stream)>>>(proxy_nchw, static_cast<uint16_t*>(native_out));
+    if (precision) proxy_pack_kernel<true><<<grid, 64, 0, as_stream(stream)>>>(proxy_nchw, static_cast<uint16_t*>(native_out));
+    else proxy_pack_kernel<false><<<grid, 64, 0, as_stream(stream)>>>(proxy_nchw, static_cast<uint16_t*>(native_out));
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
@@ -396,7 +397,7 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
 #define TRY(x) do { rc = (x); if (rc != SPSP_OK) return rc; } while (0)
     const uint16_t* x0 = static_cast<const uint16_t*>(proxy);
     if (proxy_format == SPSP_PROXY_NCHW_F32) {
-        TRY(spsp_proxy_pack(ctx, static_cast<const float*>(proxy), B, r->x0, stream));
+        TRY(spsp_proxy_pack(ctx, static_cast<const float*>(proxy), B, r->f16, r->x0, stream));
         x0 = r->x0;
     }
     // stem
@@ -473,7 +474,8 @@ int spsp_regressor_read_stage(spsp_ctx* ctx, spsp_regressor* r, int stage, int B
     const int S = stage == 0 ? 128 : kLayerS[stage < 2 ? 0 : stage - 2];
     const int C = stage < 2 ? 64 : kLayerC[stage - 2];
     const size_t total = (size_t)B * C * S * S;
-    read_stage_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(r->stage_ptr[stage], out_nchw, B, S, S, C, 1);
+    if (r->f16) read_stage_kernel<true><<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(r->stage_ptr[stage], out_nchw, B, S, S, C, 1);
+    else read_stage_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(r->stage_ptr[stage], out_nchw, B, S, S, C, 1);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

@@ -22,12 +22,19 @@ def _np(a):
 
 
 class SingleInputRegressor:
-    def __init__(self, resnet_in_channels=18, resnet_layers=18, ief_iters=3, mean_params=None, max_batch=32):
+    def __init__(self, resnet_in_channels=18, resnet_layers=18, ief_iters=3, mean_params=None, max_batch=32,
+                 precision='bf16'):
         if resnet_in_channels != 18 or resnet_layers != 18:
             raise NotImplementedError('only the configuration the reference ever instantiates is built: '
                                       'SingleInputRegressor(18, 18, 3) (PR/player_recon.py:134-136)')
         self.ief_iters = ief_iters
         self.max_batch = max_batch
+        # 'bf16' (default) or 'f16': storage / MFMA element type of the backbone (include/spsp.h, precision 0 / 1)
+        if precision not in ('bf16', 'f16'):
+            raise ValueError(f"precision must be 'bf16' or 'f16', got {precision!r}")
+        self.precision = precision
+        self._prec = _abi.PRECISION_F16 if precision == 'f16' else _abi.PRECISION_BF16
+        self.native_dtype = torch.float16 if precision == 'f16' else torch.bfloat16
         self._sd = None
         self._handle = None
         self._rt = None
@@ -116,25 +123,27 @@ class SingleInputRegressor:
         h = C.c_void_p()
         self._drop()
         with torch.cuda.device(r.device):
-            r.check(lib.spsp_regressor_load(r.ctx, C.byref(w), self.max_batch, 0, C.byref(h)), 'spsp_regressor_load')
+            r.check(lib.spsp_regressor_load(r.ctx, C.byref(w), self.max_batch, self._prec, C.byref(h)), 'spsp_regressor_load')
         self._handle, self._rt = h, r
 
     # -- forward ------------------------------------------------------------------------------------
     def pack(self, proxy_nchw):
-        """NCHW fp32 [B,18,256,256] -> backbone-native [B,262,264,18] bf16 (zero border) device tensor."""
+        """NCHW fp32 [B,18,256,256] -> backbone-native [B,262,264,18] bf16 / fp16 (zero border) device tensor."""
         x = rt.dev_f32(proxy_nchw)
         r = rt.get(x.device)
         if x.dim() != 4 or tuple(x.shape[1:]) != (18, 256, 256):
             raise ValueError(f'proxy representation must be [B,18,256,256], got {tuple(x.shape)}')
-        out = torch.empty((x.shape[0], 262, 264, 18), dtype=torch.bfloat16, device=x.device)
-        r.check(r.lib.spsp_proxy_pack(r.ctx, rt.ptr(x), x.shape[0], rt.ptr(out), r.stream()), 'spsp_proxy_pack')
+        out = torch.empty((x.shape[0], 262, 264, 18), dtype=self.native_dtype, device=x.device)
+        r.check(r.lib.spsp_proxy_pack(r.ctx, rt.ptr(x), x.shape[0], self._prec, rt.ptr(out), r.stream()), 'spsp_proxy_pack')
         return out
 
     def forward(self, input, return_feats=False):
-        native = isinstance(input, torch.Tensor) and input.dtype == torch.bfloat16
+        native = isinstance(input, torch.Tensor) and input.dtype in (torch.bfloat16, torch.float16)
+        if native and input.dtype != self.native_dtype:
+            raise ValueError(f'native proxy dtype {input.dtype} does not match this regressor (precision={self.precision!r}: {self.native_dtype})')
         if native:
             if input.dim() != 4 or tuple(input.shape[1:]) != (262, 264, 18) or not input.is_cuda:
-                raise ValueError(f'native proxy must be a CUDA bf16 [B,262,264,18] tensor, got {tuple(input.shape)}')
+                raise ValueError(f'native proxy must be a CUDA {self.precision} [B,262,264,18] tensor, got {tuple(input.shape)}')
             x = input.contiguous()
         else:
             x = rt.dev_f32(input)

@@ -37,6 +37,14 @@ def regressor_gpu(regressor_sd_np, dev):
     return reg.to(dev).eval()
 
 
+@pytest.fixture(scope='module')
+def regressor_gpu_f16(regressor_sd_np, dev):
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=32, precision='f16')
+    reg.load_state_dict(regressor_sd_np)
+    return reg.to(dev).eval()
+
+
 def test_native_library_is_the_code_that_runs():
     lib = _abi.load()
     assert lib.spsp_version().startswith(b'spsp')
@@ -234,12 +242,17 @@ def test_fit_is_deterministic_and_batch_independent(smpl_gpu, dev):
 
 
 # ---------------------------------------------------------------- regressor (a2-a4)
+@pytest.mark.parametrize('precision', ['bf16', 'f16'])
 @pytest.mark.parametrize('B', [3, 8])    # 3: ragged, layer4 falls back to the ring kernel; 8: every patch kernel incl. the 8x8 one
-def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_sd_np, dev, B):
+def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_gpu_f16, regressor_sd_np, dev, B, precision):
+    """Every stage of the backbone against the oracle rounding weights and stored activations to the SAME element
+    type at the same points (bf16: precision 0; fp16: precision 1)."""
     from oracle import regressor as OR
     x, _ = S.proxy_crops(B, seed=4)
+    regressor_gpu = regressor_gpu_f16 if precision == 'f16' else regressor_gpu
+    ulp = 1.0 if precision == 'bf16' else 0.125          # fp16 has 3 more mantissa bits
     cam, pose, shape, feats = regressor_gpu(torch.from_numpy(x).to(dev), return_feats=True)
-    f_emu, stages = OR.encoder_forward(regressor_sd_np, x, emulate_bf16=True, return_stages=True)
+    f_emu, stages = OR.encoder_forward(regressor_sd_np, x, emulate_bf16=precision, return_stages=True)
     names = ['conv1', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4']
     for si, n in enumerate(names):
         got = regressor_gpu.read_stage(si, B).cpu()
@@ -248,9 +261,9 @@ def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_
         err = (got - ref).abs().max().item()
         scale = ref.abs().max().item()
         # same bf16 rounding points, different fp32 summation order: a few 1-ulp(bf16) flips at most
-        assert err <= 0.02 * scale, f'stage {n}: max err {err} vs scale {scale}'
-        assert (got - ref).abs().mean().item() <= 5e-4 * scale, f'stage {n}: mean err'   # (bf16-vs-fp32 gap is ~2.4e-3)
-    np.testing.assert_allclose(feats.cpu().numpy(), f_emu.numpy(), rtol=0, atol=3e-3 * f_emu.abs().max().item())
+        assert err <= 0.02 * ulp * scale, f'stage {n}: max err {err} vs scale {scale}'
+        assert (got - ref).abs().mean().item() <= 5e-4 * ulp * scale, f'stage {n}: mean err'   # (bf16-vs-fp32 gap is ~2.4e-3)
+    np.testing.assert_allclose(feats.cpu().numpy(), f_emu.numpy(), rtol=0, atol=3e-3 * ulp * f_emu.abs().max().item())
     c_e, p_e, s_e = OR.ief_forward(regressor_sd_np, feats.cpu(), S.mean_params())
     np.testing.assert_allclose(cam.cpu().numpy(), c_e.numpy(), atol=2e-5)       # IEF itself is fp32
     np.testing.assert_allclose(pose.cpu().numpy(), p_e.numpy(), atol=2e-5)
@@ -273,6 +286,25 @@ def test_regressor_against_reference_golden_outputs(regressor_gpu, golden, dev):
         assert np.abs(got[0, :2] - ref).max() < 0.05 * np.abs(ref).max() + 1e-3
 
 
+def test_regressor_f16_mode_against_reference_golden_outputs(regressor_gpu_f16, golden, dev):
+    """precision 1 (fp16 storage, f16 MFMA) vs the reference module's fp32 outputs: 10x tighter than the bf16 mode
+    -- 5e-4 on (cam, pose6d, shape), 0.25 % of the feature scale -- and a dtype check on the native input."""
+    g = golden('regressor')
+    x, _ = S.proxy_crops(int(g['crops_batch']), seed=int(g['crops_seed']))
+    xt = torch.from_numpy(x).to(dev)
+    cam, pose, shape, feats = regressor_gpu_f16(xt, return_feats=True)
+    assert np.abs(feats.cpu().numpy() - g['feats']).max() < 2.5e-3 * np.abs(g['feats']).max()
+    assert np.abs(cam.cpu().numpy() - g['cam']).max() < 5e-4
+    assert np.abs(pose.cpu().numpy() - g['pose']).max() < 5e-4
+    assert np.abs(shape.cpu().numpy() - g['shape']).max() < 5e-4
+    native = regressor_gpu_f16.pack(xt)
+    assert native.dtype == torch.float16
+    c2, p2, s2 = regressor_gpu_f16(native)
+    assert torch.equal(cam, c2) and torch.equal(pose, p2) and torch.equal(shape, s2)
+    with pytest.raises(ValueError):
+        regressor_gpu_f16(native.to(torch.bfloat16))
+
+
 def test_regressor_native_input_batch_invariance_and_limits(regressor_gpu, dev):
     x, _ = S.proxy_crops(32, seed=8)
     xt = torch.from_numpy(x).to(dev)
@@ -292,14 +324,18 @@ def test_regressor_native_input_batch_invariance_and_limits(regressor_gpu, dev):
 
 
 # ---------------------------------------------------------------- end to end (a13)
-def test_end_to_end_against_oracle_pipeline(regressor_gpu, smpl_gpu, oracle_smpl, regressor_sd_np, smpl_model_np, dev):
+@pytest.mark.parametrize('precision', ['bf16', 'f16'])
+def test_end_to_end_against_oracle_pipeline(regressor_gpu, regressor_gpu_f16, smpl_gpu, oracle_smpl, regressor_sd_np, smpl_model_np, dev,
+                                            precision):
     """crop -> regressor -> rot6d -> 50-iter pose+shape fit -> SMPL: vertices vs the CPU oracle run on the SAME
-    regressor outputs within 1e-3 m (fit + SMPL kernels), and vs the all-fp32 oracle with the bf16 backbone
-    deviation reported (stated tolerance 1e-2 m for the bf16 path)."""
+    regressor outputs within 1e-3 m (fit + SMPL kernels), and vs the ALL-fp32 oracle (the reference CPU path end to
+    end): regressor -> SMPL within 2.5e-4 m with the fp16 backbone (precision 1) and 4e-3 m with bf16 (precision 0, the
+    benchmark's configuration); after the fit the median player is within 1e-3 m (fp16), maxima bounded (see below)."""
+    regressor_gpu = regressor_gpu_f16 if precision == 'f16' else regressor_gpu
     from soccerplayershapepose_amd.player_recon import reconstruct_players
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
     from oracle import regressor as OR, geometry as G, fit as OF, smpl as OS
-    B = 3
+    B = 5
     x, jin = S.proxy_crops(B, seed=12)
     xt = torch.from_numpy(x).to(dev)
     cam0, pose0, shape0 = regressor_gpu(xt)
@@ -320,19 +356,33 @@ def test_end_to_end_against_oracle_pipeline(regressor_gpu, smpl_gpu, oracle_smpl
         with torch.no_grad():
             v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
         worst = max(worst, (res.vertices[i].cpu() - v[0]).abs().max().item())
+    print(f'fit + SMPL kernels vs oracle fit + SMPL from identical regressor outputs ({precision}): {worst:.3e} m')
     assert worst < 1e-3, f'fit+SMPL kernels vs oracle from identical regressor outputs: {worst}'
-    # (ii) everything fp32 on the CPU
+    # (ii) everything fp32 on the CPU (the reference path end to end)
     cam_o, pose_o, shape_o = OR.regressor_forward(regressor_sd_np, x, S.mean_params())
     R_o = G.rot6d_to_rotmat(pose_o).view(B, 24, 3, 3)
-    worst2 = 0.0
+    with torch.no_grad():
+        pre_o = oracle_smpl(body_pose=R_o[:, 1:], global_orient=R_o[:, :1], betas=shape_o).vertices
+    pre = smpl_gpu(full_pose=R0, betas=shape0).vertices.cpu()
+    dev_pre = (pre - pre_o).abs().max().item()
+    per_player = []
     for i in range(B):
         r = OF.fit_pose_shape(oracle_smpl, R_o[i:i + 1, 1:], R_o[i:i + 1, :1], shape_o[i:i + 1], tgt[i], cam_o[i:i + 1], iters=50)
         body, Gm, be, ca, _ = r['last']
         with torch.no_grad():
             v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
-        worst2 = max(worst2, (res.vertices[i].cpu() - v[0]).abs().max().item())
-    print(f'end-to-end max vertex deviation, bf16 backbone vs all-fp32 oracle: {worst2:.3e} m')
-    assert worst2 < 1e-2
+        per_player.append((res.vertices[i].cpu() - v[0]).abs().max().item())
+    print(f'{precision} backbone vs all-fp32 oracle, max vertex deviation: regressor -> SMPL {dev_pre:.3e} m; '
+          f'after the 50-iteration fit per player {[f"{d:.2e}" for d in per_player]} m')
+    # Backbone -> SMPL (no optimiser in between): the north-star 1e-3 m holds with fp16 storage (measured 9e-5);
+    # bf16 storage is the benchmark configuration, ~1.5e-3.
+    assert dev_pre < (2.5e-4 if precision == 'f16' else 4e-3)
+    # After the fit the figure also contains the reference algorithm's own sensitivity: Adam's update is
+    # lr * m/(sqrt(v)+eps) ~ +-1e-3 per iteration however small the gradient, so for weakly observed joints a 1e-4
+    # change of the regressor outputs can flip update signs and end 1e-3 apart (the all-fp32 oracle itself, fed its own
+    # outputs + N(0, 1e-4): up to 1.1e-3).  Median within 1e-3 for fp16, bounded maxima for both.
+    assert sorted(per_player)[len(per_player) // 2] < (1e-3 if precision == 'f16' else 5e-3)
+    assert max(per_player) < (3e-3 if precision == 'f16' else 1e-2)
 
 
 def test_predict_3d_mirror(regressor_gpu, smpl_gpu, dev):
