@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth', type=int, default=4, help='pipeline slots (HIP streams); 1 = strictly serial steps')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16'], help='backbone storage / MFMA element type')
+    ap.add_argument('--from-detections', action='store_true',
+                    help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
     ap.add_argument('--graphs', action='store_true', help='replay each slot\'s step from a captured HIP graph (no in-region kernel events)')
     ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
@@ -114,7 +116,7 @@ def main():
     r = rt.get(dev)
 
     # ---- synthetic inputs (seed 1234 + rank), resident in HBM in the backbone-native layout ----
-    x_nchw, _ = S.proxy_crops(B, seed=1234 + rank)
+    x_nchw, joints_in = S.proxy_crops(B, seed=1234 + rank)
     native = reg.pack(torch.from_numpy(x_nchw).to(dev))
     # fit targets: the regressor-initialised model, perturbed + 1 px noise; set-up, untimed
     cam0, pose0, shape0 = reg(native)
@@ -128,10 +130,18 @@ def main():
     tgt = torch.from_numpy(tgt_np[:, :, :2]).float().to(dev).contiguous()
     torch.cuda.synchronize()
 
+    if args.from_detections:
+        from soccerplayershapepose_amd.predict.predict_3D import create_proxy_representation_batch
+        sil_dev = torch.from_numpy(np.repeat(np.repeat(x_nchw[:, 0], 2, axis=1), 2, axis=2).astype(np.uint8)).to(dev)
+        joints_dev = torch.from_numpy(joints_in.astype(np.float32)).to(dev)
+        assert torch.equal(create_proxy_representation_batch(sil_dev, joints_dev, precision=args.precision).view(torch.int16),
+                           native.view(torch.int16))
+
     def step():
-        # one batch through the WHOLE path on the next pipeline slot (its own stream): regressor -> rot6d ->
-        # 50-iter fit -> SMPL forward [-> all-gather of the records]
-        res = pipe.submit(native, tgt, fit=args.fit, iters=FIT_ITERS)
+        # one batch through the WHOLE path on the next pipeline slot (its own stream): [proxy builder ->] regressor ->
+        # rot6d -> 50-iter fit -> SMPL forward [-> all-gather of the records]
+        inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=args.precision) if args.from_detections else native
+        res = pipe.submit(inp, tgt, fit=args.fit, iters=FIT_ITERS)
         if world > 1:
             with torch.cuda.stream(res.stream):
                 res.gathered = all_gather_records(pack_record(res.cam, res.rotmats, res.betas), world * B)
@@ -227,7 +237,8 @@ def main():
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
-                       'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs)},
+                       'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs),
+                       'proxy_built_on_gpu': bool(args.from_detections)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
             # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's
             # event pair also spans the time its workgroups share CUs with other batches' kernels; that figure is

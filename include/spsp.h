@@ -111,6 +111,16 @@ size_t spsp_proxy_native_bytes(void);
 /* NCHW fp32 -> native layout in the element type of `precision` (writes interior AND border). */
 int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, int precision, void* native_out, void* stream);
 
+/* Proxy-representation builder (replaces create_proxy_representation, PR/predict/predict_3D.py:67-81, and
+ * convert_2Djoints_to_gaussian_heatmaps, PR/utils/label_conversions.py:58-87, for a batch): device silhouettes
+ * [B,512,512] (uint8 or fp32, values 0/1) + device joints2D [B,17,joints_stride] (x, y[, conf]; 512-px space)
+ * -> native layout [B,262,264,18] in the element type of `precision`, border included.  Bit-identical to
+ * spsp_proxy_pack applied to the reference routine's [18,256,256] output. */
+#define SPSP_SIL_U8  0
+#define SPSP_SIL_F32 1
+int spsp_proxy_build(spsp_ctx* ctx, const void* silhouettes, int sil_format, const float* joints2d, int joints_stride,
+                     int B, int precision, void* native_out, void* stream);
+
 /* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
                            float* cam, float* pose6d, float* betas, float* feats, void* stream);

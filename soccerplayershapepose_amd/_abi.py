@@ -22,6 +22,7 @@ FIT_MASK_POSE_SHAPE = FIT_GLOBAL_ORIENT | FIT_CAM | FIT_BETAS | 0x003FFE7E
 FIT_SELECT_LAST, FIT_SELECT_BEST_L2E = 0, 1
 PROXY_NCHW_F32, PROXY_NATIVE = 0, 1
 PRECISION_BF16, PRECISION_F16 = 0, 1
+SIL_U8, SIL_F32 = 0, 1
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -97,6 +98,7 @@ _PROTOS = {
     'spsp_regressor_free': (None, [_vp]),
     'spsp_proxy_native_bytes': (C.c_size_t, []),
     'spsp_proxy_pack': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'spsp_proxy_build': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spsp_regressor_read_stage': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     'spsp_rot6d_to_rotmat': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),

@@ -1,0 +1,112 @@
+// Proxy-representation builder on the GPU (the step immediately before the hot path):
+//   create_proxy_representation  PR/predict/predict_3D.py:67-81
+//   convert_2Djoints_to_gaussian_heatmaps  PR/utils/label_conversions.py:58-87
+// silhouette [512,512] + 17 detected joints (512-px space)  ->  the backbone's NATIVE input
+// [262][264][18] bf16 / fp16 (channel 0 = nearest-resized silhouette, channels 1..17 = 16x16 Gaussian stamps),
+// written once, border included, so neither the fp32 NCHW tensor [18,256,256] (4.7 MB per crop) nor
+// spsp_proxy_pack ever exist.  HBM-bound: 2.49 MB written + 0.26 MB read per crop.
+//
+// Reference quirks kept bit for bit (tests/test_gpu_parity.py compares with pack(create_proxy_representation)):
+//   * joints are scaled by 0.5 and TRUNCATED to int16 (predict_3D.py:73-76);
+//   * the stamp is sampled on linspace(-8, 8, 16): no exact 0, peak 0.9826 (label_conversions.py:63-71);
+//   * a joint is drawn iff -8 < cx, cy < 263; the end index is min(255, c + 8), so row / column 255 is never
+//     written by any stamp (label_conversions.py:66, 74-77);
+//   * value at (y, x) = G[y - cy + 8][x - cx + 8] (the start/clip arithmetic of :73-85 reduces to this).
+#include <cmath>
+
+#include "common.hpp"
+#include "conv_elem.hpp"
+
+namespace {
+using namespace spsp;
+
+constexpr int kWH = 256, kPad = 3, kHp = SPSP_PROXY_NATIVE_H, kWp = SPSP_PROXY_NATIVE_W, kC = 18, kJ = 17;
+
+struct ProxyTable { float g[16][16]; };
+
+template <bool F16, typename SIL>
+__global__ __launch_bounds__(256) void proxy_build_kernel(const SIL* __restrict__ sil, const float* __restrict__ joints,
+                                                        int joints_stride, ProxyTable tab, uint16_t* __restrict__ dst) {
+    __shared__ float sG[16][16];
+    __shared__ int sC[kJ][2];
+    __shared__ __attribute__((aligned(16))) uint32_t sOut[256 * 9];      // the workgroup's 256 pixels x 36 bytes, contiguous in HBM
+    // 256 consecutive pixels of the padded [262][264] image per workgroup (row-major), one pixel = 36 bytes per thread
+    const int b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+    const int yp = pix / kWp, xp = pix - yp * kWp;
+    sG[threadIdx.x >> 4][threadIdx.x & 15] = tab.g[threadIdx.x >> 4][threadIdx.x & 15];
+    if (threadIdx.x < kJ * 2) {
+        const int j = threadIdx.x >> 1, c = threadIdx.x & 1;
+        const float v = joints[((size_t)b * kJ + j) * joints_stride + c] * 0.5f;
+        sC[j][c] = (int)(short)(int)truncf(v);            // numpy .astype(np.int16): truncation toward zero
+    }
+    __syncthreads();
+    const int x = xp - kPad, y = yp - kPad;
+    const bool inside = x >= 0 && x < kWH && y >= 0 && y < kWH;       // (yp >= 262: tail of the last workgroup, never stored)
+    float v[kC];
+#pragma unroll
+    for (int c = 0; c < kC; ++c) v[c] = 0.f;
+    if (inside) {
+        v[0] = (float)sil[((size_t)b * 512 + 2 * y) * 512 + 2 * x];     // cv2.INTER_NEAREST at an exact factor 2
+        if (x < kWH - 1 && y < kWH - 1) {
+#pragma unroll
+            for (int j = 0; j < kJ; ++j) {
+                const int cx = sC[j][0], cy = sC[j][1];
+                const int dx = x - cx + 8, dy = y - cy + 8;
+                const bool drawn = min(cx, cy) > -8 && max(cx, cy) < kWH - 1 + 8;
+                if (drawn && (unsigned)dx < 16u && (unsigned)dy < 16u) v[1 + j] = sG[dy][dx];
+            }
+        }
+    }
+    // a lane's 36 bytes are not a power of two: stored directly, one wave-instruction scatters 64 dwords over 2.3 KB.
+    // Stage the pixels in LDS and leave as whole 16-byte pieces, consecutive lanes -> consecutive addresses.
+#pragma unroll
+    for (int c = 0; c < kC; c += 2) sOut[threadIdx.x * 9 + c / 2] = Elem<F16>::pack2(v[c], v[c + 1]);
+    __syncthreads();
+    const int npix = min(256, kHp * kWp - (int)blockIdx.x * 256);
+    uint4* d = reinterpret_cast<uint4*>(dst + ((size_t)b * kHp * kWp + (size_t)blockIdx.x * 256) * kC);
+    for (int i = threadIdx.x; i < npix * 9 / 4; i += 256) d[i] = reinterpret_cast<const uint4*>(sOut)[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int spsp_proxy_build(spsp_ctx* ctx, const void* silhouettes, int sil_format, const float* joints2d, int joints_stride, int B,
+                     int precision, void* native_out, void* stream) {
+    using namespace spsp;
+    SPSP_REQUIRE(ctx && B >= 0, "spsp_proxy_build: bad arguments");
+    if (B == 0) return SPSP_OK;
+    SPSP_REQUIRE(silhouettes && joints2d && native_out, "spsp_proxy_build: NULL argument");
+    SPSP_REQUIRE(sil_format == SPSP_SIL_U8 || sil_format == SPSP_SIL_F32, "spsp_proxy_build: unknown sil_format %d", sil_format);
+    SPSP_REQUIRE(joints_stride >= 2, "spsp_proxy_build: joints_stride=%d (need x, y [, conf])", joints_stride);
+    SPSP_REQUIRE(precision == 0 || precision == 1, "spsp_proxy_build: precision %d (0 = bf16, 1 = fp16)", precision);
+    // the stamp, exactly as label_conversions.py:63-71 evaluates it: float64, then stored into a float32 map
+    static ProxyTable tab;
+    static bool have = false;
+    if (!have) {
+        for (int a = 0; a < 16; ++a)
+            for (int c = 0; c < 16; ++c) {
+                const double ly = -8.0 + 16.0 * a / 15.0, lx = -8.0 + 16.0 * c / 15.0;
+                const double d = std::sqrt(lx * lx + ly * ly);
+                tab.g[a][c] = (float)std::exp(-(d * d / (2.0 * 4.0 * 4.0)));
+            }
+        have = true;
+    }
+    hipStream_t st = as_stream(stream);
+    dim3 grid((kHp * kWp + 255) / 256, B);
+    ProfScope ps(ctx, kKProxyBuild, st);
+    uint16_t* out = static_cast<uint16_t*>(native_out);
+    if (sil_format == SPSP_SIL_U8) {
+        const uint8_t* s = static_cast<const uint8_t*>(silhouettes);
+        if (precision) proxy_build_kernel<true, uint8_t><<<grid, 256, 0, st>>>(s, joints2d, joints_stride, tab, out);
+        else proxy_build_kernel<false, uint8_t><<<grid, 256, 0, st>>>(s, joints2d, joints_stride, tab, out);
+    } else {
+        const float* s = static_cast<const float*>(silhouettes);
+        if (precision) proxy_build_kernel<true, float><<<grid, 256, 0, st>>>(s, joints2d, joints_stride, tab, out);
+        else proxy_build_kernel<false, float><<<grid, 256, 0, st>>>(s, joints2d, joints_stride, tab, out);
+    }
+    SPSP_HIP_CHECK(hipGetLastError());
+    return SPSP_OK;
+}
+
+}  // extern "C"

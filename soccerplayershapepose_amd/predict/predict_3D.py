@@ -4,7 +4,8 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from .. import config
+from .. import _abi, config
+from .. import runtime as rt
 from ..utils.cam_utils import orthographic_project_to_pixels
 from ..utils.label_conversions import convert_2Djoints_to_gaussian_heatmaps
 from ..utils.rigid_transform_utils import rot6d_to_rotmat
@@ -21,6 +22,35 @@ def create_proxy_representation(silhouette, joints2D, in_wh, out_wh):
     heatmaps = convert_2Djoints_to_gaussian_heatmaps(j.astype(np.int16), out_wh)
     proxy = np.concatenate([silhouette[:, :, None], heatmaps], axis=-1)
     return np.transpose(proxy, [2, 0, 1])
+
+
+def create_proxy_representation_batch(silhouettes, joints2D, precision='bf16'):
+    """The same routine for a batch ON THE GPU, emitting the backbone's native input directly:
+    silhouettes [B,512,512] (uint8 / bool / float32, values 0/1) and joints2D [B,17,2|3] (x, y[, conf]; 512-px
+    space) -> [B,262,264,18] bf16 / fp16 device tensor, bit-identical to
+    `regressor.pack(stack(create_proxy_representation(sil_b, joints_b, 512, 256)))`; feed it to
+    `SingleInputRegressor(precision=...)` as is.  Fixed to the reference's 512 -> 256 geometry."""
+    if precision not in ('bf16', 'f16'):
+        raise ValueError(f"precision must be 'bf16' or 'f16', got {precision!r}")
+    sil = silhouettes if isinstance(silhouettes, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(silhouettes))
+    r = rt.get(sil.device if sil.is_cuda else None)
+    if sil.dim() != 3 or tuple(sil.shape[1:]) != (512, 512):
+        raise ValueError(f'silhouettes must be [B,512,512], got {tuple(sil.shape)}')
+    if sil.dtype == torch.bool:
+        sil = sil.to(torch.uint8)
+    if sil.dtype not in (torch.uint8, torch.float32):
+        sil = sil.to(torch.float32)
+    sil = sil.to(r.device).contiguous()
+    j = rt.dev_f32(torch.as_tensor(joints2D), r.device).contiguous()
+    B = sil.shape[0]
+    if j.dim() != 3 or j.shape[0] != B or j.shape[1] != 17 or j.shape[2] < 2:
+        raise ValueError(f'joints2D must be [B,17,>=2] with B={B}, got {tuple(j.shape)}')
+    prec = _abi.PRECISION_F16 if precision == 'f16' else _abi.PRECISION_BF16
+    out = torch.empty((B, 262, 264, 18), dtype=torch.float16 if precision == 'f16' else torch.bfloat16, device=r.device)
+    fmt = _abi.SIL_U8 if sil.dtype == torch.uint8 else _abi.SIL_F32
+    r.check(r.lib.spsp_proxy_build(r.ctx, rt.ptr(sil), fmt, rt.ptr(j), j.shape[2], B, prec, rt.ptr(out), r.stream()),
+            'spsp_proxy_build')
+    return out
 
 
 def predict_3D(proxy_rep, regressor, smpl):

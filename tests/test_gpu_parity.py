@@ -468,3 +468,39 @@ def test_smpl_forward_is_bit_stable_next_to_convolutions_on_other_streams(regres
         bad += sum(0 if (torch.equal(o.vertices, ref_v) and torch.equal(o.joints, ref_j)) else 1 for o in outs)
         assert all(torch.equal(f, feats_ref) for f in feats)
     assert bad == 0, f'{bad} of {total} SMPL forwards differ from the serial result while convolutions run on other streams'
+
+
+# ---------------------------------------------------------------- proxy builder on the GPU (8f-1)
+@pytest.mark.parametrize('precision', ['bf16', 'f16'])
+def test_gpu_proxy_builder_is_bit_identical_to_the_reference_routine(regressor_gpu, regressor_gpu_f16, golden, dev, precision):
+    """spsp_proxy_build vs pack(create_proxy_representation) (the numpy mirror, itself pinned to the reference's
+    heat-map routine by tests/golden/geometry.npz): every element of the native tensor, border included -- random
+    joints, sub-pixel joints (int16 truncation), and the reference's edge cases: joints at -8 / -7 (not drawn /
+    one column), 0, 254 / 255 (last row / column never written), 262 / 263 (one column / not drawn), far outside."""
+    from soccerplayershapepose_amd.predict.predict_3D import create_proxy_representation, create_proxy_representation_batch
+    reg = regressor_gpu_f16 if precision == 'f16' else regressor_gpu
+    rng = np.random.default_rng(5)
+    B = 6
+    sil = (rng.random((B, 512, 512)) < 0.4).astype(np.uint8)
+    sil[0, ::2, ::2] = 1; sil[0, 1::2, :] = 0               # only the sampled pixels set / only the skipped ones set
+    j = np.zeros((B, 17, 3), np.float32)
+    j[:, :, :2] = rng.uniform(-40, 560, size=(B, 17, 2)).astype(np.float32)
+    j[:, :, 2] = 1
+    edge = np.array([-16, -15, -14, -1, 0, 1, 15, 16, 17, 508, 509, 510, 511, 524, 525, 526, 527], np.float32)
+    j[1, :, 0] = edge; j[1, :, 1] = 200.7
+    j[2, :, 1] = edge; j[2, :, 0] = 301.3
+    j[3, :, 0] = edge; j[3, :, 1] = edge[::-1]
+    j[4, :, :2] = np.floor(j[4, :, :2]) + 0.999                # truncation, not rounding
+    ref = np.stack([create_proxy_representation(sil[b].astype(np.float64), j[b].astype(np.float64), 512, 256) for b in range(B)])
+    want = reg.pack(torch.from_numpy(ref.astype(np.float32)).to(dev))
+    got = create_proxy_representation_batch(torch.from_numpy(sil).to(dev), torch.from_numpy(j).to(dev), precision=precision)
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    got_f = create_proxy_representation_batch(sil.astype(np.float32), j[:, :, :2], precision=precision)     # host inputs, fp32 silhouette, [B,17,2]
+    assert torch.equal(got_f.view(torch.int16), want.view(torch.int16))
+    assert want[:, 3:259, 3:259, 1:].float().amax().item() > 0.9      # stamps really drawn
+    # and it feeds the regressor directly
+    a, b = reg(got[:2]), reg(torch.from_numpy(ref[:2].astype(np.float32)).to(dev))
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    with pytest.raises(ValueError):
+        create_proxy_representation_batch(sil[:, :256], j, precision=precision)
