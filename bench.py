@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16'], help='backbone storage / MFMA element type')
     ap.add_argument('--from-detections', action='store_true',
                     help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
+    ap.add_argument('--rehearse-dist', action='store_true',
+                    help='run the N>1 code path (RCCL process group, per-step all-gather, barriers) even with one rank')
     ap.add_argument('--graphs', action='store_true', help='replay each slot\'s step from a captured HIP graph (no in-region kernel events)')
     ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
@@ -82,6 +84,12 @@ def cpu_baseline(sd, model, x_nchw, tgt, n, threads):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: native libraries write banners there (RCCL prints its version
+    # block to stdout at communicator creation), so fd 1 is pointed at stderr for the duration of the run and the
+    # result line goes to a saved copy of the original stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -89,8 +97,12 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.rehearse_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)      # nccl == RCCL on ROCm
 
     from soccerplayershapepose_amd import _abi, synthetic as S
@@ -142,13 +154,14 @@ def main():
         # rot6d -> 50-iter fit -> SMPL forward [-> all-gather of the records]
         inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=args.precision) if args.from_detections else native
         res = pipe.submit(inp, tgt, fit=args.fit, iters=FIT_ITERS)
-        if world > 1:
+        if use_dist:
             with torch.cuda.stream(res.stream):
-                res.gathered = all_gather_records(pack_record(res.cam, res.rotmats, res.betas), world * B)
+                res.gathered = all_gather_records(pack_record(res.cam, res.rotmats, res.betas), world * B,
+                                                  force_collective=True)
         return res
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -213,9 +226,11 @@ def main():
     r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
     r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = elapsed.item()
+    if use_dist:        # every rank holds every player's record, in shard order
+        assert out.gathered.shape == (world * B, 229) and torch.equal(out.gathered[rank * B:(rank + 1) * B, :3], out.cam)
     assert torch.isfinite(out.vertices).all() and out.vertices.abs().max().item() > 0.1
     kernels = read_profile(args.steps)
 
@@ -234,7 +249,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'batch-{B} 256x256 synthetic proxy crops per GPU: ResNet-18+IEF regressor ({args.precision} MFMA, '
                                    f'fp32 accumulate) -> rot6d -> {FIT_ITERS}-iter {args.fit} Adam fit -> SMPL forward '
-                                   f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if world > 1 else ''),
+                                   f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if use_dist else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs),
@@ -257,8 +272,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_sample, args.cpu_threads)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

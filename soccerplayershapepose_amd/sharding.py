@@ -22,11 +22,12 @@ def shard_range(n, world, rank):
     return start, start + sizes[rank]
 
 
-def all_gather_records(local, n_total, group=None):
+def all_gather_records(local, n_total, group=None, force_collective=False):
     """local: [n_local, 229] records of this rank's shard (shard_range order) -> [n_total, 229] on every rank.
-    Ragged shards are padded to the largest shard so a single all_gather_into_tensor suffices."""
+    Ragged shards are padded to the largest shard so a single all_gather_into_tensor suffices.  With one rank the
+    input is returned as is unless `force_collective` (rehearsal of the N>1 path on a single GPU)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local
     sizes = shard_sizes(n_total, world)
     rank = dist.get_rank(group)
