@@ -504,3 +504,49 @@ def test_gpu_proxy_builder_is_bit_identical_to_the_reference_routine(regressor_g
     assert all(torch.equal(u, v) for u, v in zip(a, b))
     with pytest.raises(ValueError):
         create_proxy_representation_batch(sil[:, :256], j, precision=precision)
+
+
+# ---------------------------------------------------------------- BASELINE configs 4 and 5 as parity cases
+def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """Config 4: one match frame = 22 players in one call (ragged w.r.t. every tile size).  Config 5: a short clip in
+    which frame t's fit starts from frame t-1's result (`single_view_optimization` given the previous record as the
+    warm start) while the targets move smoothly; two of the players are followed through the whole clip
+    by the CPU oracle doing the same chain.  Tolerance: 2e-4 on raw parameters per frame, 1e-3 m on final vertices."""
+    from soccerplayershapepose_amd.player_recon import reconstruct_players, single_view_optimization
+    from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
+    from oracle import fit as OF, smpl as OS
+    N, T, follow = 22, 3, (0, 21)
+    x, _ = S.proxy_crops(N, seed=31)
+    xt = torch.from_numpy(x).to(dev)
+    cam0, pose0, shape0 = regressor_gpu(xt)
+    R0 = rot6d_to_rotmat(pose0).view(N, 24, 3, 3)
+    # a smooth random walk of the "true" pose (2 deg / frame) drives the detected joints of every frame
+    Rt_true = R0.cpu().numpy().astype(np.float64)
+    targets = []
+    for t in range(T):
+        step, b2, _ = S.pose_params(N, seed=40 + t, body_deg=2, global_deg=2)
+        Rt_true = step.astype(np.float64) @ Rt_true
+        _, jp = OS.smpl_forward_np(smpl_model_np, Rt_true.astype(np.float32), shape0.cpu().numpy())
+        targets.append(S.fit_targets_from_joints(jp, cam0.cpu().numpy() * np.array([1.05, 1, 1], np.float32), seed=50 + t))
+    # frame 0: the whole path from the crops; frames 1..: warm start from the previous record
+    res = reconstruct_players(regressor_gpu, smpl_gpu, xt, targets[0], fit='pose_shape', iters=50)
+    assert res.vertices.shape == (N, 6890, 3) and torch.isfinite(res.vertices).all()
+    body, orient, betas, cam = res.rotmats[:, 1:], res.rotmats[:, :1], res.betas, res.cam
+    # the oracle follows two players through the same chain, started from the same regressor outputs
+    o = {i: (R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape0[i:i + 1].cpu(), cam0[i:i + 1].cpu()) for i in follow}
+    for t in range(T):
+        if t > 0:
+            rec = single_view_optimization(smpl_gpu, body, orient, betas, cam, targets[t], interation=50)
+            body, orient, betas, cam = rec.body_pose, rec.global_orient, rec.betas, rec.cam_wp
+        for i in follow:
+            r = OF.fit_pose_shape(oracle_smpl, o[i][0], o[i][1], o[i][2], targets[t][i], o[i][3], iters=50)
+            ob, og, obe, oc, _ = r['last']
+            o[i] = (ob.detach(), og.detach(), obe.detach(), oc.detach())
+            assert (body[i].cpu() - ob[0]).abs().max().item() < 2e-4, f'frame {t} player {i}: body pose'
+            assert (orient[i].cpu() - og[0]).abs().max().item() < 2e-4
+            assert (betas[i].cpu() - obe[0]).abs().max().item() < 2e-4 and (cam[i].cpu() - oc[0]).abs().max().item() < 2e-4
+    out = smpl_gpu(body_pose=body, global_orient=orient, betas=betas)
+    for i in follow:
+        with torch.no_grad():
+            v = oracle_smpl(body_pose=o[i][0], global_orient=o[i][1], betas=o[i][2]).vertices[0]
+        assert (out.vertices[i].cpu() - v).abs().max().item() < 1e-3
