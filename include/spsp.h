@@ -71,6 +71,29 @@ int         spsp_profile_num_kernels(void);
 const char* spsp_profile_kernel_name(int id);
 int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);
 
+/* ---- relation module: replaces PoseRelationModule (PR/models/regressor_relate.py:9-139; used between rot6d and
+ *      the fit at PR/PyTorch3DTest.py:3758-3759 when use_relate) -- the players of ONE frame attend to each other.
+ *      Host arrays in nn.Linear layout: W*.weight [out][in], W*.bias [out]. */
+#define SPSP_NUM_RELATIONS 27
+typedef struct {
+    const float* wg_weight;   /* [1][8]   */
+    const float* wg_bias;     /* [1]      */
+    const float* wk_weight;   /* [8][216] */
+    const float* wk_bias;     /* [8]      */
+    const float* wq_weight;   /* [8][216] */
+    const float* wq_bias;     /* [8]      */
+    const float* wv_weight;   /* [8][216] */
+    const float* wv_bias;     /* [8]      */
+} spsp_relate_unit;
+typedef struct { spsp_relate_unit unit[SPSP_NUM_RELATIONS]; } spsp_relate_weights;
+typedef struct spsp_relate spsp_relate;
+int  spsp_relate_load(spsp_ctx* ctx, const spsp_relate_weights* w, int max_players, spsp_relate** out);
+void spsp_relate_free(spsp_relate* h);
+/* pose_rotmats [N,24,3,3] and boxes [N,4] = (x_min, y_min, x_max, y_max) on the device -> out [N,24,3,3]
+ * (may not alias pose_rotmats).  N = all players of the frame (the operator couples them: shard BY FRAME). */
+int  spsp_relate_forward(spsp_ctx* ctx, spsp_relate* h, const float* pose_rotmats, const float* boxes, int N,
+                         float* out, void* stream);
+
 /* ---- regressor: replaces SingleInputRegressor (PR/models/regressor.py:13-48) ------------------ */
 typedef struct {
     const float* weight;        /* host [cout,cin,k,k] fp32 (torch Conv2d layout), no bias (resnet.py:30-36) */

@@ -51,7 +51,38 @@ def import_reference():
     mods.cam_utils, mods.joints2d_utils, mods.label_conversions = cam_utils, joints2d_utils, label_conversions
     mods.Loss = HomoscedasticUncertaintyWeightedMultiTaskLoss
     mods.Tracker = TrainingLossesAndMetricsTracker
+    from models.regressor_relate import PoseRelationModule
+    mods.PoseRelationModule = PoseRelationModule
     return mods
+
+
+def gen_relate(ref):
+    """PoseRelationModule (PR/models/regressor_relate.py) on a 22-player frame and on a 2-player one.  Its
+    __PositionalEmbedding calls `.cuda()` on a freshly made arange (:63); there is no GPU in the build container,
+    so for the duration of this call Tensor.cuda is a no-op -- the arithmetic that runs is the reference's own."""
+    from oracle import relate as ORL
+    sd = S.relation_state_dict(seed=0)
+    net = ref.PoseRelationModule()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    net.eval()
+    out = {}
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, n in (('frame22', 22), ('pair', 2)):
+            R, _, _ = S.pose_params(n, seed=60 + n)
+            boxes = S.frame_boxes(n, seed=61 + n)
+            with torch.no_grad():
+                y = net([torch.from_numpy(R), torch.from_numpy(boxes)])
+                emb = getattr(net, '_PoseRelationModule__PositionalEmbedding')(torch.from_numpy(boxes))
+            mine = ORL.pose_relation_forward(sd, R, boxes)
+            print(f'relate {tag}: reference vs restatement max |d| = {(y - mine).abs().max().item():.3e}, '
+                  f'embedding {(emb - ORL.positional_embedding(boxes)).abs().max().item():.3e}, '
+                  f'moved the pose by {(y - torch.from_numpy(R)).abs().max().item():.3f}')
+            out.update({f'{tag}_R': R, f'{tag}_boxes': boxes, f'{tag}_out': y.numpy(), f'{tag}_emb': emb.numpy()})
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez(os.path.join(OUT, 'relate.npz'), weights_seed=0, **out)
 
 
 def gen_regressor(ref):
@@ -198,8 +229,14 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     cwd = os.getcwd()
+    only = set(sys.argv[1:])                      # e.g. `python -m oracle.gen_golden relate` regenerates one file
     ref = import_reference()
-    gen_regressor(ref)
-    gen_geometry(ref)
+    if not only or 'regressor' in only:
+        gen_regressor(ref)
+    if not only or 'geometry' in only:
+        gen_geometry(ref)
+    if not only or 'relate' in only:
+        gen_relate(ref)
     os.chdir(cwd)
-    gen_smpl_fit()
+    if not only or 'smpl_fit' in only:
+        gen_smpl_fit()

@@ -37,6 +37,17 @@ class RegressorWeights(C.Structure):
                 ('init_params', _fp), ('ief_iters', C.c_int)]
 
 
+NUM_RELATIONS = 27
+
+
+class RelateUnit(C.Structure):
+    _fields_ = [(f'{w}_{k}', _fp) for w in ('wg', 'wk', 'wq', 'wv') for k in ('weight', 'bias')]
+
+
+class RelateWeights(C.Structure):
+    _fields_ = [('unit', RelateUnit * NUM_RELATIONS)]
+
+
 class SmplArrays(C.Structure):
     _fields_ = [('v_template', _fp), ('shapedirs', _fp), ('posedirs', _fp), ('J_regressor', _fp),
                 ('lbs_weights', _fp), ('parents', _ip), ('vertex_joint_ids', _ip),
@@ -98,6 +109,9 @@ _PROTOS = {
     'spsp_regressor_free': (None, [_vp]),
     'spsp_proxy_native_bytes': (C.c_size_t, []),
     'spsp_proxy_pack': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'spsp_relate_load': (C.c_int, [_vp, C.POINTER(RelateWeights), C.c_int, C.POINTER(_vp)]),
+    'spsp_relate_free': (None, [_vp]),
+    'spsp_relate_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     'spsp_proxy_build': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spsp_regressor_read_stage': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),

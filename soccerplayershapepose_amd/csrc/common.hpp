@@ -88,7 +88,7 @@ enum KernelId {
     kKConvWres,        // conv3x3_wres_kernel (layer1)
     kKConvRing,        // conv_ring_kernel<...> (stride-2 / 1x1 convs, fallbacks)
     kKConvIgemm,       // conv_igemm_kernel<...> (first generation, fallbacks)
-    kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKNumKernels
+    kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate, kKNumKernels
 };
 struct ProfRec { int id; hipEvent_t start, stop; };
 }  // namespace spsp

@@ -92,14 +92,20 @@ def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp,
 
 
 def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape', iters=50, lr=None,
-                        select_mode=_abi.FIT_SELECT_LAST, return_vertices2d=False):
+                        select_mode=_abi.FIT_SELECT_LAST, return_vertices2d=False, pose_relation=None, boxes=None):
     """The hot path end to end for one batch (`evaluate_model_2d` core, `PR/PyTorch3DTest.py:3738-3776`):
         proxy_rep [B,18,256,256] -> regressor -> rot6d -> fit ('camera' = optimize_camera per player,
         'pose_shape' = single_view_optimization per player, None = skip) -> SMPL forward.
+    `pose_relation` (a `models.regressor_relate.PoseRelationModule`) + `boxes` insert the reference's optional
+    cross-player refinement between rot6d and the fit.
     Returns cam [B,3], rotmats [B,24,3,3], betas [B,10], vertices [B,6890,3], joints [B,90,3], translation."""
     cam, pose6d, betas = regressor(proxy_rep)
     B = cam.shape[0]
     R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
+    if pose_relation is not None:       # `use_relate`, PR/PyTorch3DTest.py:3758-3759: the batch is ONE frame's players
+        if boxes is None:
+            raise ValueError('reconstruct_players: pose_relation needs boxes= [B,4] (x_min, y_min, x_max, y_max)')
+        R = pose_relation([R, boxes])
     if fit is not None:
         variant = {'camera': 0, 'pose_shape': 1}[fit]
         fit_players(smpl, R, betas, cam, joints2D, variant=variant, iters=iters, lr=lr, select_mode=select_mode)

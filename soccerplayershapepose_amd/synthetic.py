@@ -263,6 +263,35 @@ def gaussian_heatmaps(joints2D, img_wh, std=4):
     return heatmaps
 
 
+def relation_state_dict(seed=0):
+    """State dict (numpy, 216 arrays) of `PoseRelationModule` (`PR/models/regressor_relate.py`): 27 relation units
+    x {WG [1,8], WK/WQ/WV [8,216]} + biases.  Scales keep the geometry gate WG around 1 (so relu/log/clamp all see
+    both branches over a frame) and the attention logits O(1)."""
+    sd = {}
+    for r in range(27):
+        p = f'relation_module.relation.{r}'
+        sd[p + '.WG.weight'] = (0.6 * hash_normal(8, p + '.WG.w', seed)).reshape(1, 8).astype(np.float32)
+        sd[p + '.WG.bias'] = (0.3 + 0.4 * hash_normal(1, p + '.WG.b', seed)).astype(np.float32)
+        for n, sc in (('WK', 1.0), ('WQ', 1.0), ('WV', 0.15)):
+            sd[f'{p}.{n}.weight'] = (sc * hash_normal(8 * 216, f'{p}.{n}.w', seed) / np.sqrt(216.0)).reshape(8, 216).astype(np.float32)
+            sd[f'{p}.{n}.bias'] = (0.05 * hash_normal(8, f'{p}.{n}.b', seed)).astype(np.float32)
+    return sd
+
+
+def frame_boxes(n, seed=0, frame_wh=(1920, 1080)):
+    """n player boxes (x_min, y_min, x_max, y_max) in a 1080p frame; two players share a centre column and two
+    have identical boxes, so the reference's clamp(|delta|, 1e-3) branch and log(1) = 0 are exercised."""
+    u = hash_uniform(4 * n, 'boxes', seed).reshape(n, 4)
+    w = 40 + 80 * u[:, 2]
+    h = 90 + 160 * u[:, 3]
+    cx = 100 + (frame_wh[0] - 200) * u[:, 0]
+    cy = 150 + (frame_wh[1] - 300) * u[:, 1]
+    if n >= 4:
+        cx[1] = cx[0]
+        cx[3], cy[3], w[3], h[3] = cx[2], cy[2], w[2], h[2]
+    return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], axis=1).astype(np.float32)
+
+
 def proxy_crops(batch, seed=0, wh=256):
     """[B,18,wh,wh] float32 NCHW proxy representations: channel 0 a binary capsule silhouette,
     channels 1..17 joint heat-maps at integer locations inside the silhouette bbox.

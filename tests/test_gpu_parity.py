@@ -550,3 +550,42 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
         with torch.no_grad():
             v = oracle_smpl(body_pose=o[i][0], global_orient=o[i][1], betas=o[i][2]).vertices[0]
         assert (out.vertices[i].cpu() - v).abs().max().item() < 1e-3
+
+
+# ---------------------------------------------------------------- PoseRelationModule (8f-2)
+def test_pose_relation_module_against_reference_golden_and_oracle(regressor_gpu, smpl_gpu, golden, dev):
+    """csrc/relate.hip vs the reference's PoseRelationModule outputs (tests/golden/relate.npz, 22-player frame and a
+    2-player one) and vs the oracle on a fresh 37-player frame; tolerance 5e-6 on matrix entries (fp32; sin/cos/log/exp
+    of different libms).  Then the operator in its place in the pipeline (between rot6d and the fit)."""
+    from soccerplayershapepose_amd.models.regressor_relate import PoseRelationModule
+    from soccerplayershapepose_amd.player_recon import reconstruct_players
+    from oracle import relate as ORL
+    g = golden('relate')
+    sd = S.relation_state_dict(seed=int(g['weights_seed']))
+    rel = PoseRelationModule(max_players=64).load_state_dict(sd).to(dev).eval()
+    for tag in ('frame22', 'pair'):
+        R, boxes = torch.from_numpy(g[f'{tag}_R']).to(dev), torch.from_numpy(g[f'{tag}_boxes']).to(dev)
+        out = rel([R, boxes])
+        assert out.shape == R.shape
+        np.testing.assert_allclose(out.cpu().numpy(), g[f'{tag}_out'], atol=5e-6, rtol=0)
+        assert torch.equal(R.cpu(), torch.from_numpy(g[f'{tag}_R']))        # input untouched
+    R, _, _ = S.pose_params(37, seed=71)
+    boxes = S.frame_boxes(37, seed=72)
+    want = ORL.pose_relation_forward(sd, R, boxes).numpy()
+    np.testing.assert_allclose(rel([R, boxes]).cpu().numpy(), want, atol=5e-6, rtol=0)       # host inputs are accepted
+    with pytest.raises(ValueError):
+        rel([R[:5], boxes[:4]])
+    with pytest.raises(ValueError):
+        PoseRelationModule(max_players=8).load_state_dict(sd).to(dev)([R, boxes])
+    with pytest.raises(KeyError):
+        PoseRelationModule().load_state_dict({k: v for k, v in sd.items() if 'relation.3.WQ' not in k})
+    # in the pipeline: regressor -> rot6d -> relation -> (no fit) -> SMPL equals the stages run by hand
+    from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
+    x, _ = S.proxy_crops(6, seed=9)
+    xt, bx = torch.from_numpy(x).to(dev), torch.from_numpy(S.frame_boxes(6, seed=3)).to(dev)
+    res = reconstruct_players(regressor_gpu, smpl_gpu, xt, None, fit=None, pose_relation=rel, boxes=bx)
+    cam, pose, shape = regressor_gpu(xt)
+    R2 = rel([rot6d_to_rotmat(pose).view(6, 24, 3, 3), bx])
+    assert torch.equal(res.rotmats, R2) and torch.equal(res.vertices, smpl_gpu(full_pose=R2, betas=shape).vertices)
+    with pytest.raises(ValueError):
+        reconstruct_players(regressor_gpu, smpl_gpu, xt, None, fit=None, pose_relation=rel)
