@@ -11,6 +11,7 @@
 // Workgroup: 4 output rows x 128 pixels x 64 channels, 8 waves (two per SIMD), wave = (row, 64-pixel half),
 // wave tile 64 px x 64 ch on v_mfma_f32_16x16x32_bf16; the [64 x 128] weight slab of each kernel row streams
 // through a 2-stage LDS-DMA ring.  All fragment addresses are ONE per-lane base + immediates.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv.hpp"
@@ -171,6 +172,145 @@ __global__ __launch_bounds__(512) void conv1_patch_kernel(const ConvArgs a) {
     }
 }
 
+
+// ---- second variant: HALF-WIDTH tiles, two workgroups per CU ------------------------------------------------------
+// The kernel above owns its CU alone (153 KB of LDS): its 121 KB patch load, its K loop and its 64 KB of output stores
+// run one after the other, four times per CU.  Here a workgroup takes 4 output rows x 64 pixels x 64 channels with
+// 4 waves (one output row each): the 13 x 133-pixel input patch is 61 KB (rows are gathered with per-lane source
+// addresses; the LDS image keeps the 36-byte pixel pitch, row pitch 4800 B), the weights stream as fourteen
+// [64 x 64] half-row slabs through a 2 x 8 KB ring, 77 KB in all -- so TWO workgroups share a CU and one loads or
+// stores while the other multiplies (2048 workgroups = 8 per CU).  Fragment reads are software-pipelined one
+// half-step ahead of the MFMAs (two register sets), as in conv_patch.hip.
+constexpr int kHRowB = 4800;                               // 133.3 px x 36 B, a multiple of 16
+constexpr int kHPieces = (kPatchRows * kHRowB + 1023) / 1024;   // 61
+constexpr int kHPatchB = kHPieces * 1024;                  // 62 464
+constexpr int kHWStage = 64 * 128;                         // [64 n][64 k]
+constexpr int kHLds = kHPatchB + 2 * kHWStage;             // 78 848
+
+template <bool F16>
+__global__ __launch_bounds__(256) void conv1_half_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    unsigned char* const ring = smem + kHPatchB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = gridDim.x;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+    const int b = tile >> 6, oy0 = ((tile >> 1) & 31) * 4, ox0 = (tile & 1) * 64;
+    const uint16_t* const w_ptr = a.w;
+
+    // ---- patch: 13 rows x 4800 B; byte o of the LDS image comes from input row o / 4800, byte o % 4800 of the run
+    //      that starts at input pixel 2*ox0 (4608 B into the row for the right half: 16-byte aligned) ----
+    const unsigned char* const pbase = reinterpret_cast<const unsigned char*>(a.in) +
+                                       ((size_t)b * a.in_img + (size_t)(2 * oy0) * a.in_row) * 2 + (size_t)(2 * ox0) * 36;
+#pragma unroll
+    for (int i = 0; i < (kHPieces + 3) / 4; ++i) {
+        const int p = wave + 4 * i;
+        if (p < kHPieces) {
+            const int o = (p * 64 + lane) * 16, row = o / kHRowB, col = o - row * kHRowB;
+            dma16(reinterpret_cast<const uint16_t*>(pbase + (size_t)row * kRowB + col), smem + p * 1024);
+        }
+    }
+    // ---- weight ring: stage g = K-elements [64 g, 64 g + 64) of all 64 rows; piece = 8 rows x 128 B ----
+    const int drow = lane >> 3, dchunk = lane & 7;
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + drow;
+        w_src[i] = w_ptr + (size_t)row * (7 * 128) + ((dchunk ^ (row & 7)) * 8);
+    }
+    auto issue_w = [&](int g, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(w_src[i] + g * 64, ring + buf * kHWStage + (wave * 2 + i) * 1024);
+    };
+    issue_w(0, 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    const uint32_t w_lane = frow * 128 + ((fq ^ (frow & 7)) * 16);            // ks = 1: ^ 64
+    const uint32_t x_lane = smem_base + (2 * wave) * kHRowB + frow * 72 + fq * 16;
+
+    bf16x8 wfr[2][2][4], xfr[2][2][4];
+#define SPSP_C1_READ(G, SET)                                                                              \
+    {                                                                                                     \
+        const uint32_t wbase_ = smem_base + kHPatchB + ((G) & 1) * kHWStage;                              \
+        const uint32_t xa_ = x_lane + ((G) >> 1) * kHRowB + ((G) & 1) * 128;                              \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
+            const uint32_t wa_ = wbase_ + (w_lane ^ (kk * 64));                                           \
+            wfr[SET][kk][0] = lds_read_b128<0>(wa_);                                                      \
+            wfr[SET][kk][1] = lds_read_b128<2048>(wa_);                                                   \
+            wfr[SET][kk][2] = lds_read_b128<4096>(wa_);                                                   \
+            wfr[SET][kk][3] = lds_read_b128<6144>(wa_);                                                   \
+            xfr[SET][kk][0] = lds_read_2xb64<0>(xa_ + kk * 64);                                           \
+            xfr[SET][kk][1] = lds_read_2xb64<16 * 72>(xa_ + kk * 64);                                     \
+            xfr[SET][kk][2] = lds_read_2xb64<32 * 72>(xa_ + kk * 64);                                     \
+            xfr[SET][kk][3] = lds_read_2xb64<48 * 72>(xa_ + kk * 64);                                     \
+        }                                                                                                 \
+    }
+#define SPSP_C1_MFMA(SET)                                                                                 \
+    {                                                                                                     \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+                    acc[i][j] = Elem<F16>::mfma(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j]);             \
+    }
+#define SPSP_C1_STEP(G, SET)                                                                              \
+    {                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    /* fragments of step G-1 are in registers */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        wait_vmcnt<0>();                                       /* stage G (and, at G = 0, the patch) landed */ \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if ((G) + 1 < 14) issue_w((G) + 1, ((G) + 1) & 1);     /* into the slot step G-1 was read from */  \
+        SPSP_C1_READ(G, SET)                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if ((G) > 0) SPSP_C1_MFMA((SET) ^ 1)                                                              \
+    }
+    SPSP_C1_STEP(0, 0) SPSP_C1_STEP(1, 1) SPSP_C1_STEP(2, 0) SPSP_C1_STEP(3, 1) SPSP_C1_STEP(4, 0) SPSP_C1_STEP(5, 1)
+    SPSP_C1_STEP(6, 0) SPSP_C1_STEP(7, 1) SPSP_C1_STEP(8, 0) SPSP_C1_STEP(9, 1) SPSP_C1_STEP(10, 0) SPSP_C1_STEP(11, 1)
+    SPSP_C1_STEP(12, 0) SPSP_C1_STEP(13, 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    SPSP_C1_MFMA(1)
+#undef SPSP_C1_STEP
+#undef SPSP_C1_MFMA
+#undef SPSP_C1_READ
+
+    // ---- epilogue: bias + ReLU, staged through LDS (tile [256 px][128 B], chunk ^= pixel & 7), whole-line stores ----
+    float4 bias_r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias_r[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + fq * 4);
+    __syncthreads();                                       // patch and ring are dead
+    unsigned char* const outT = smem;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int tp = wave * 64 + j * 16 + frow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 bv = bias_r[i];
+            const f32x4 c = acc[i][j];
+            float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            *reinterpret_cast<uint2*>(outT + tp * 128 + (((i * 2 + (fq >> 1)) ^ (tp & 7)) * 16) + (fq & 1) * 8) =
+                make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {                       // 256 px x 8 chunks / 256 threads
+        const int idx = tid + it * 256, tp = idx >> 3, c = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(outT + tp * 128 + ((c ^ (tp & 7)) * 16));
+        const size_t o = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)(oy0 + (tp >> 6)) * a.out_row +
+                         (size_t)(ox0 + (tp & 63)) * a.out_pix;
+        *reinterpret_cast<uint4*>(a.out + o + c * 8) = v;
+    }
+}
+
 }  // namespace
 
 namespace spsp {
@@ -188,6 +328,21 @@ int launch_conv1_patch(const ConvArgs& a, hipStream_t st) {
         set = true;
     }
     const int B = a.M / (128 * 128);
+    static const bool half = getenv("SPSP_CONV1_HALF") ? atoi(getenv("SPSP_CONV1_HALF")) != 0 : true;
+    if (half) {
+        static bool hset = false;
+        if (!hset) {
+            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_half_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kHLds));
+            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_half_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kHLds));
+            hset = true;
+        }
+        if (a.f16) conv1_half_kernel<true><<<dim3(B * 64), 256, kHLds, st>>>(a);
+        else conv1_half_kernel<false><<<dim3(B * 64), 256, kHLds, st>>>(a);
+        SPSP_HIP_CHECK(hipGetLastError());
+        return SPSP_OK;
+    }
     if (a.f16) conv1_patch_kernel<true><<<dim3(B * 32), 512, kLds, st>>>(a);
     else conv1_patch_kernel<false><<<dim3(B * 32), 512, kLds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
