@@ -85,6 +85,8 @@ enum KernelId {
     kKPatchW16Big,     // conv3x3_patch_kernel<false, 2, 5>  (8-wave workgroups)
     kKPatchW8Small,    // conv3x3_patch_kernel<true, 1, 3>
     kKPatchW8Big,      // conv3x3_patch_kernel<true, 2, 5>
+    kKPatchW16Grp,     // conv3x3_patch_kernel<false, 2, 6>  (8 waves, one barrier per kernel row)
+    kKPatchW8Grp,      // conv3x3_patch_kernel<true, 2, 6>
     kKConvWres,        // conv3x3_wres_kernel (layer1)
     kKConvRing,        // conv_ring_kernel<...> (stride-2 / 1x1 convs, fallbacks)
     kKConvIgemm,       // conv_igemm_kernel<...> (first generation, fallbacks)

@@ -42,6 +42,7 @@ static const char* const kKernelNames[spsp::kKNumKernels] = {
     "conv1_patch_kernel", "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel",
     "conv3x3_patch_kernel<false, 1, 3>", "conv3x3_patch_kernel<false, 2, 5>",
     "conv3x3_patch_kernel<true, 1, 3>", "conv3x3_patch_kernel<true, 2, 5>",
+    "conv3x3_patch_kernel<false, 2, 6>", "conv3x3_patch_kernel<true, 2, 6>",
     "conv3x3_wres_kernel", "conv_ring_kernel", "conv_igemm_kernel", "fc_kernel", "init_params_kernel+split_params_kernel",
     "proxy_pack_kernel", "proxy_build_kernel", "rot6d_kernel", "fit_kernel", "smpl_chain_kernel", "smpl_skin_kernel",
     "smpl_extra_joints_kernel", "relate_project_kernel+relate_attend_kernel"};

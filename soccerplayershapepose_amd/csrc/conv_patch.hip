@@ -219,6 +219,56 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 
     CSTAMP(0);
     issue_patch(0);
+    if constexpr (kNS == 6) {
+        // ---- grouped ring: the three slabs of one kernel row land together, ONE barrier per three K-steps ----------
+        // Ring = 2 halves x 3 slabs.  Group g = (chunk, kernel row): at its start every wave has the fragments of the
+        // previous group in registers (lgkmcnt(0)) and its own DMA pieces of group g landed (vmcnt(0): nothing younger
+        // is in flight yet); after the barrier the slabs of group g+1 are issued into the half group g-1 was read
+        // from, then the three taps run back to back -- 48 MFMAs per wave between barriers instead of 16.
+        const int ngroups = 3 * nchunks;
+        auto issue_group = [&](int g) {
+            const int gch = g / 3, gr = g - gch * 3;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nchunks + gch, (g & 1) * 3 + t);
+        };
+        issue_group(0);
+#define SPSP_GTAP(TAP, SET, SLOT, FIRST)                                                                  \
+    {                                                                                                     \
+        SPSP_READ_FRAGS(TAP, SET, SLOT)                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (!(FIRST)) SPSP_MFMA_SET((SET) ^ 1)                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#define SPSP_GROUP(R, P0, CH, HALF)                                                                       \
+    {                                                                                                     \
+        const int g_ = (CH) * 3 + (R);                                                                    \
+        wait_vmcnt<0>();                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                     \
+        if ((R) == 0 && (CH) > 0) {                                                                       \
+            /* chunk boundary: every wave is past its last read of the old patch; refill it, run the pending */ \
+            /* MFMAs of the previous tap underneath, then wait for the patch (older than the slabs issued next) */ \
+            issue_patch(CH);                                                                              \
+            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
+            SPSP_MFMA_SET(((P0) & 1) ^ 1)                                                                 \
+            if (g_ + 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
+            __builtin_amdgcn_s_barrier();                                                                 \
+            SPSP_GTAP(0, (P0) & 1, (HALF) * 3 + 0, true)                                                  \
+        } else {                                                                                          \
+            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
+            SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (HALF) * 3 + 0, (R) == 0 && (CH) == 0)       \
+        }                                                                                                 \
+        SPSP_GTAP((R) * 3 + 1, ((R) * 3 + 1 + (P0)) & 1, (HALF) * 3 + 1, false)                           \
+        SPSP_GTAP((R) * 3 + 2, ((R) * 3 + 2 + (P0)) & 1, (HALF) * 3 + 2, false)                           \
+    }
+        // group parity: g = 3 ch + r -> half = g & 1; a chunk has 3 groups, so the half of row r flips with ch
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            SPSP_GROUP(0, 0, ch, 0) SPSP_GROUP(1, 0, ch, 1) SPSP_GROUP(2, 0, ch, 0)
+            if (ch + 1 < nchunks) { SPSP_GROUP(0, 1, ch + 1, 1) SPSP_GROUP(1, 1, ch + 1, 0) SPSP_GROUP(2, 1, ch + 1, 1) }
+        }
+#undef SPSP_GROUP
+#undef SPSP_GTAP
+    } else {
     int issued = 0;
     for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w((issued % 9) * nchunks + issued / 9, issued);
     auto issue_next = [&]() {
@@ -263,6 +313,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     for (int ch = 0; ch < nchunks; ch += 2) {
         SPSP_CHUNK(0, ch)
         if (ch + 1 < nchunks) SPSP_CHUNK(1, ch + 1)
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -428,8 +479,9 @@ int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream) {
     SPSP_REQUIRE(!a.pool_out || a.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
     // variant 0: 4 waves, ring 3 (65-74 KB LDS: two workgroups per CU) -- many-workgroup layers
     // variant 1: 8 waves (wave pairs split each K-step), ring 5 -- few-workgroup deep layers, one workgroup per CU
-    if (a.Wo == 8) return variant == 0 ? launch<true, 1, 3>(a, stream) : launch<true, 2, 5>(a, stream);
-    return variant == 0 ? launch<false, 1, 3>(a, stream) : launch<false, 2, 5>(a, stream);
+    // variant 3: 8 waves, grouped ring of 2 x 3 slabs -- one barrier per kernel row (three K-steps)
+    if (a.Wo == 8) return variant == 0 ? launch<true, 1, 3>(a, stream) : variant == 3 ? launch<true, 2, 6>(a, stream) : launch<true, 2, 5>(a, stream);
+    return variant == 0 ? launch<false, 1, 3>(a, stream) : variant == 3 ? launch<false, 2, 6>(a, stream) : launch<false, 2, 5>(a, stream);
 }
 
 }  // namespace spsp

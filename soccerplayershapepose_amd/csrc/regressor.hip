@@ -203,7 +203,7 @@ struct spsp_regressor {
     bool use_patch;        // 3x3 stride-1 convs through conv_patch.hip
     bool conv1_patch;      // stem through conv1_patch.hip
     bool use_wres;         // layer1 through conv_wres.hip
-    int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs)
+    int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs), 3: 1 + grouped ring
 };
 
 namespace {
@@ -239,7 +239,8 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     if (L >= 0 && r->use_patch && conv_patch_supported(a)) {
         const int v = r->patch_variant[L];
-        const int kid3 = a.Wo == 8 ? (v ? kKPatchW8Big : kKPatchW8Small) : (v ? kKPatchW16Big : kKPatchW16Small);
+        const int kid3 = a.Wo == 8 ? (v == 3 ? kKPatchW8Grp : v ? kKPatchW8Big : kKPatchW8Small)
+                                   : (v == 3 ? kKPatchW16Grp : v ? kKPatchW16Big : kKPatchW16Small);
         ProfScope ps(ctx, kid3, st);
         return launch_conv_patch(a, v, st);
     }
@@ -339,10 +340,10 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         if (const char* pe = getenv("SPSP_CONV_WRES")) r->use_wres = atoi(pe) != 0;
         r->conv1_patch = true;
         if (const char* pe = getenv("SPSP_CONV1_PATCH")) r->conv1_patch = atoi(pe) != 0;
-        const int def_v[4] = {1, 1, 1, 1};   // measured: the 8-wave variant wins on every stage at 32 crops
+        const int def_v[4] = {3, 3, 3, 3};   // measured at 32 crops: 8 waves + grouped ring (one barrier per kernel row) wins on every stage
         for (int L = 0; L < 4; ++L) r->patch_variant[L] = def_v[L];
         if (const char* pv = getenv("SPSP_PATCH_VARIANT"))       // e.g. "0111"
-            for (int L = 0; L < 4 && pv[L]; ++L) r->patch_variant[L] = pv[L] == '1';
+            for (int L = 0; L < 4 && pv[L]; ++L) r->patch_variant[L] = pv[L] - '0';
         if (const char* env = getenv("SPSP_CONV_PLAN")) {
             std::string e(env);
             size_t pos = 0;
