@@ -104,11 +104,11 @@ __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __rest
 
 // ---- IEF fully-connected layer (fp32): out[b][n] = act(bias[n] + sum_k x[b][k] W[n][k]) (+ out, if accumulate)
 // The input row is the concatenation [x0[b][0:K0] | x1[b][0:K1]] (torch.cat([feat, params]), ief_module.py:55,59).
-// Workgroup = 4 waves = 8 neurons x 8 players: the 8 input rows are staged in LDS once (coalesced), each wave
-// streams the weight rows of its 2 neurons (lanes stride over k, all loads of a row in flight together) and
+// Workgroup = 4 waves = 4 neurons x 8 players: the 8 input rows are staged in LDS once (coalesced), each wave
+// loads the weight row of its neuron first (lanes stride over k; the L2 latency runs under the staging) and
 // reduces over lanes.  Latency-bound (9 dependent launches per forward); fp32 VALU keeps the regressor outputs
 // at reference precision downstream of the bf16 backbone.
-constexpr int kFcPB = 8, kFcNPW = 2, kFcNB = 4 * kFcNPW;
+constexpr int kFcPB = 8, kFcNPW = 1, kFcNB = 4 * kFcNPW;
 template <int K0, int K1>
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                  const float* __restrict__ W, const float* __restrict__ bias, int N, int B,
@@ -117,40 +117,50 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x0, c
     __shared__ float xs[kFcPB][K + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = blockIdx.y * kFcPB;
+    // the weight rows of this wave's neurons first: their L2 latency runs under the staging of the input rows
+    float w[kFcNPW][KI];
+#pragma unroll
+    for (int q = 0; q < kFcNPW; ++q) {
+        const int n = min((int)blockIdx.x * kFcNB + wave * kFcNPW + q, N - 1);
+        const float* wr = W + (size_t)n * K;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) { const int k = lane + 64 * i; w[q][i] = k < K ? wr[k] : 0.f; }
+    }
     for (int i = threadIdx.x; i < kFcPB * K; i += 256) {
         const int p = i / K, k = i - p * K;
         const int b = min(b0 + p, B - 1);
         xs[p][k] = k < K0 ? x0[(size_t)b * K0 + k] : x1[(size_t)b * K1 + (k - K0)];
     }
     __syncthreads();
+    float acc[kFcNPW][kFcPB];
+#pragma unroll
+    for (int q = 0; q < kFcNPW; ++q)
+#pragma unroll
+        for (int p = 0; p < kFcPB; ++p) acc[q][p] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+        const int k = min(lane + 64 * i, K - 1);
+#pragma unroll
+        for (int p = 0; p < kFcPB; ++p) {
+            const float xv = xs[p][k];
+#pragma unroll
+            for (int q = 0; q < kFcNPW; ++q) acc[q][p] = fmaf(w[q][i], xv, acc[q][p]);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < kFcNPW; ++q) {
         const int n = blockIdx.x * kFcNB + wave * kFcNPW + q;
-        if (n >= N) break;
-        const float* wr = W + (size_t)n * K;
-        float w[KI];
-#pragma unroll
-        for (int i = 0; i < KI; ++i) { const int k = lane + 64 * i; w[i] = k < K ? wr[k] : 0.f; }
-        float acc[kFcPB];
-#pragma unroll
-        for (int p = 0; p < kFcPB; ++p) acc[p] = 0.f;
-#pragma unroll
-        for (int i = 0; i < KI; ++i) {
-            const int k = min(lane + 64 * i, K - 1);
-#pragma unroll
-            for (int p = 0; p < kFcPB; ++p) acc[p] = fmaf(w[i], xs[p][k], acc[p]);
-        }
 #pragma unroll
         for (int p = 0; p < kFcPB; ++p) {
-            float v = acc[p];
+            float v = acc[q][p];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            acc[p] = v;
+            acc[q][p] = v;
         }
-        if (lane < kFcPB && b0 + lane < B) {
+        if (n < N && lane < kFcPB && b0 + lane < B) {
             float v = 0.f;
 #pragma unroll
-            for (int p = 0; p < kFcPB; ++p) v = (lane == p) ? acc[p] : v;
+            for (int p = 0; p < kFcPB; ++p) v = (lane == p) ? acc[q][p] : v;
             v += bias[n];
             if (relu) v = fmaxf(v, 0.f);
             float* o = out + (size_t)(b0 + lane) * out_stride + n;
