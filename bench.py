@@ -197,7 +197,8 @@ def main():
     # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all have the
     # same shape: the stem (1 launch/step) and the 3x3 stride-1 kernels (every 3x3/1 conv of ResNet-18 has
     # 150 994 944 MACs per crop, whatever its layer)
-    cands = {'conv1_patch_kernel': FLOP_CONV1 * B, 'conv_igemm_kernel<128, 64, 128, 8>': FLOP_CONV1 * B}
+    cands = {'conv1_half_kernel': FLOP_CONV1 * B, 'conv1_patch_kernel': FLOP_CONV1 * B,
+             'conv_igemm_kernel<128, 64, 128, 8>': FLOP_CONV1 * B}
     for k in kernels_iso:
         if k.startswith('conv3x3_'):
             cands[k] = FLOP_L1CONV * B

@@ -17,7 +17,12 @@ import sys
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
-    return re.sub(r'\(.*$', '', name)
+    name = re.sub(r'\(.*$', '', name)
+    # the last template argument of the conv kernels is the element type (false = bf16, true = fp16); the library's
+    # profile names (spsp_profile_kernel_name) leave it out
+    name = re.sub(r'<(false|true)>$', '', name)
+    name = re.sub(r', (false|true)>$', '>', name)
+    return name
 
 
 def per_kernel(path):

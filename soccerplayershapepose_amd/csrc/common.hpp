@@ -81,6 +81,7 @@ inline float bf16_to_f32_host(uint16_t h) {
 namespace spsp {
 enum KernelId {
     kKConv1Patch = 0, kKConv1Igemm, kKMaxpool,
+    kKConv1Half,       // conv1_half_kernel (stem, half-width tiles, two workgroups per CU)
     kKPatchW16Small,   // conv3x3_patch_kernel<false, 1, 3>  (4-wave workgroups)
     kKPatchW16Big,     // conv3x3_patch_kernel<false, 2, 5>  (8-wave workgroups)
     kKPatchW8Small,    // conv3x3_patch_kernel<true, 1, 3>

@@ -39,7 +39,7 @@ void spsp_destroy(spsp_ctx* ctx) {
 }
 
 static const char* const kKernelNames[spsp::kKNumKernels] = {
-    "conv1_patch_kernel", "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel",
+    "conv1_patch_kernel", "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel", "conv1_half_kernel",
     "conv3x3_patch_kernel<false, 1, 3>", "conv3x3_patch_kernel<false, 2, 5>",
     "conv3x3_patch_kernel<true, 1, 3>", "conv3x3_patch_kernel<true, 2, 5>",
     "conv3x3_patch_kernel<false, 2, 6>", "conv3x3_patch_kernel<true, 2, 6>",

@@ -50,5 +50,6 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);
 
 // conv1_patch.hip: the 7x7/2 stem with an LDS-resident 13-row input patch (4 output rows x 128 px x 64 ch per workgroup)
 int launch_conv1_patch(const ConvArgs& a, hipStream_t stream);
+bool conv1_uses_half_tiles();   // true: conv1_half_kernel (default), false: conv1_patch_kernel (SPSP_CONV1_HALF=0)
 
 }  // namespace spsp

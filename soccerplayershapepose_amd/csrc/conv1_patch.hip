@@ -315,6 +315,11 @@ __global__ __launch_bounds__(256) void conv1_half_kernel(const ConvArgs a) {
 
 namespace spsp {
 
+bool conv1_uses_half_tiles() {
+    static const bool half = getenv("SPSP_CONV1_HALF") ? atoi(getenv("SPSP_CONV1_HALF")) != 0 : true;
+    return half;
+}
+
 int launch_conv1_patch(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(a.N == 64 && a.Ho == 128 && a.Wo == 128 && a.nsteps == 7 && a.stride == 2 && a.in_off == 0 &&
                      a.in_pix == 18 && a.in_row == 264 * 18,
@@ -328,8 +333,7 @@ int launch_conv1_patch(const ConvArgs& a, hipStream_t st) {
         set = true;
     }
     const int B = a.M / (128 * 128);
-    static const bool half = getenv("SPSP_CONV1_HALF") ? atoi(getenv("SPSP_CONV1_HALF")) != 0 : true;
-    if (half) {
+    if (conv1_uses_half_tiles()) {
         static bool hset = false;
         if (!hset) {
             SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_half_kernel<false>),

@@ -268,7 +268,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
         }
     }
     if (ci == 0 && r->conv1_patch) {
-        ProfScope ps(ctx, kKConv1Patch, st);
+        ProfScope ps(ctx, conv1_uses_half_tiles() ? kKConv1Half : kKConv1Patch, st);
         return launch_conv1_patch(a, st);
     }
     const int kid = tile == kTileConv1 ? kKConv1Igemm : kKConvIgemm;

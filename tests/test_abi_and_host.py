@@ -51,7 +51,8 @@ def test_profile_kernel_names_and_native_layout_size():
     lib = _abi.load()
     n = lib.spsp_profile_num_kernels()
     names = [lib.spsp_profile_kernel_name(i).decode() for i in range(n)]
-    assert 'fit_kernel' in names and 'conv1_patch_kernel' in names and sum(k.startswith('conv3x3_patch_kernel') for k in names) == 4 and 'conv3x3_wres_kernel' in names
+    assert 'fit_kernel' in names and 'conv1_patch_kernel' in names and 'conv1_half_kernel' in names and 'conv3x3_wres_kernel' in names
+    assert sum(k.startswith('conv3x3_patch_kernel') for k in names) == 6 and len(set(names)) == n
     assert lib.spsp_proxy_native_bytes() == 262 * 264 * 18 * 2
 
 
