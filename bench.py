@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='crops per GPU per step')
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
