@@ -53,7 +53,7 @@ def parse():
     ap.add_argument('--rehearse-dist', action='store_true',
                     help='run the N>1 code path (RCCL process group, per-step all-gather, barriers) even with one rank')
     ap.add_argument('--graphs', action='store_true', help='replay each slot\'s step from a captured HIP graph (no in-region kernel events)')
-    ap.add_argument('--cpu-sample', type=int, default=16, help='players timed through the CPU oracle')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='players timed through the CPU oracle (64: ~12 s on 16 threads)')
     ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
     return ap.parse_args()
 
@@ -66,13 +66,14 @@ def cpu_baseline(sd, model, x_nchw, tgt, n, threads):
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     threads = torch.get_num_threads()
     osmpl = OS.OracleSMPL(model)
-    n = min(n, x_nchw.shape[0])
+    idx = [i % x_nchw.shape[0] for i in range(n)]           # the batch's players, cycled if the sample is larger
     t0 = time.perf_counter()
-    cam, pose, shape = OR.regressor_forward(sd, x_nchw[:n], S.mean_params())
+    parts = [OR.regressor_forward(sd, x_nchw[idx[i:i + 32]], S.mean_params()) for i in range(0, n, 32)]
+    cam, pose, shape = (torch.cat([p[k] for p in parts]) for k in range(3))
     R = G.rot6d_to_rotmat(pose).view(n, 24, 3, 3)
     t1 = time.perf_counter()
     for i in range(n):
-        r = OF.fit_pose_shape(osmpl, R[i:i + 1, 1:], R[i:i + 1, :1], shape[i:i + 1], tgt[i], cam[i:i + 1], iters=FIT_ITERS)
+        r = OF.fit_pose_shape(osmpl, R[i:i + 1, 1:], R[i:i + 1, :1], shape[i:i + 1], tgt[idx[i]], cam[i:i + 1], iters=FIT_ITERS)
         body, Gm, be, ca, _ = r['last']
         with torch.no_grad():
             osmpl(body_pose=body, global_orient=Gm, betas=be)
