@@ -220,6 +220,26 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant /* 0 = A camera, 1 
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream);
 
+/* ---- the whole path in one call: the core of evaluate_model_2d (PR/PyTorch3DTest.py:3738-3776) ----------------
+ * proxy -> regressor -> rot6d -> [relation module, if `relate`] -> [fit, if `fit`] -> SMPL forward -> translation
+ * [-> packed record].  Issues the stage launches in order on `stream`; every buffer is a caller-owned device
+ * buffer.  cam / pose6d / betas / rotmats are required; vertices, joints, translation, record may be NULL (skipped);
+ * relate_tmp [B,216] is required with `relate`.  With a fit, cam / rotmats / betas hold the FITTED values. */
+typedef struct {
+    float* cam;          /* [B,3]        */
+    float* pose6d;       /* [B,144]      regressor output (not touched by the fit) */
+    float* betas;        /* [B,10]       */
+    float* rotmats;      /* [B,24,3,3]   */
+    float* vertices;     /* [B,6890,3]   or NULL */
+    float* joints;       /* [B,90,3]     or NULL */
+    float* translation;  /* [B,3]        or NULL */
+    float* record;       /* [B,229]      or NULL: [cam | R | betas], the all-gather payload */
+    float* relate_tmp;   /* [B,216]      scratch for the relation module, or NULL */
+} spsp_pipeline_out;
+int spsp_pipeline(spsp_ctx* ctx, spsp_regressor* regressor, spsp_smpl* smpl, spsp_relate* relate, const void* proxy,
+                  int proxy_format, const float* boxes, const float* joints2d, const spsp_fit_config* fit, int B,
+                  float focal, float resolution, const spsp_pipeline_out* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,11 @@ class FitConfig(C.Structure):
                 ('img_wh', C.c_float), ('loss_wh', C.c_float), ('select_mode', C.c_int)]
 
 
+class PipelineOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('cam', 'pose6d', 'betas', 'rotmats', 'vertices', 'joints', 'translation',
+                                          'record', 'relate_tmp')]
+
+
 def f32(a):
     """C-contiguous float32 numpy view/copy + its ctypes pointer (keep the array alive!)."""
     a = np.ascontiguousarray(a, dtype=np.float32)
@@ -109,6 +114,8 @@ _PROTOS = {
     'spsp_regressor_free': (None, [_vp]),
     'spsp_proxy_native_bytes': (C.c_size_t, []),
     'spsp_proxy_pack': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'spsp_pipeline': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.POINTER(FitConfig), C.c_int, C.c_float,
+                               C.c_float, C.POINTER(PipelineOut), _vp]),
     'spsp_relate_load': (C.c_int, [_vp, C.POINTER(RelateWeights), C.c_int, C.POINTER(_vp)]),
     'spsp_relate_free': (None, [_vp]),
     'spsp_relate_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),

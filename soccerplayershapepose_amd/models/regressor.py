@@ -137,6 +137,28 @@ class SingleInputRegressor:
         r.check(r.lib.spsp_proxy_pack(r.ctx, rt.ptr(x), x.shape[0], self._prec, rt.ptr(out), r.stream()), 'spsp_proxy_pack')
         return out
 
+    def prepare_input(self, input):
+        """Validated device tensor + proxy_format for spsp_regressor_forward / spsp_pipeline."""
+        native = isinstance(input, torch.Tensor) and input.dtype in (torch.bfloat16, torch.float16)
+        if native and input.dtype != self.native_dtype:
+            raise ValueError(f'native proxy dtype {input.dtype} does not match this regressor (precision={self.precision!r}: {self.native_dtype})')
+        if native:
+            if input.dim() != 4 or tuple(input.shape[1:]) != (262, 264, 18) or not input.is_cuda:
+                raise ValueError(f'native proxy must be a CUDA {self.precision} [B,262,264,18] tensor, got {tuple(input.shape)}')
+            x = input.contiguous()
+        else:
+            x = rt.dev_f32(input)
+            if x.dim() != 4 or tuple(x.shape[1:]) != (18, 256, 256):
+                raise ValueError(f'proxy representation must be [B,18,256,256], got {tuple(x.shape)}')
+        self._load(rt.get(x.device))
+        if x.shape[0] > self.max_batch:
+            raise ValueError(f'batch {x.shape[0]} exceeds max_batch {self.max_batch} given at construction')
+        return x, (_abi.PROXY_NATIVE if native else _abi.PROXY_NCHW_F32)
+
+    @property
+    def handle(self):
+        return self._handle
+
     def forward(self, input, return_feats=False):
         native = isinstance(input, torch.Tensor) and input.dtype in (torch.bfloat16, torch.float16)
         if native and input.dtype != self.native_dtype:

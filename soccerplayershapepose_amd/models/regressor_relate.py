@@ -78,6 +78,10 @@ class PoseRelationModule:
             r.check(r.lib.spsp_relate_load(r.ctx, C.byref(w), self.max_players, C.byref(h)), 'spsp_relate_load')
         self._handle, self._rt = h, r
 
+    @property
+    def handle(self):
+        return self._handle
+
     def forward(self, input):
         pose_params, bboxes = input
         pose = rt.dev_f32(pose_params)

@@ -99,22 +99,41 @@ def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape
     `pose_relation` (a `models.regressor_relate.PoseRelationModule`) + `boxes` insert the reference's optional
     cross-player refinement between rot6d and the fit.
     Returns cam [B,3], rotmats [B,24,3,3], betas [B,10], vertices [B,6890,3], joints [B,90,3], translation."""
-    cam, pose6d, betas = regressor(proxy_rep)
-    B = cam.shape[0]
-    R = rot6d_to_rotmat(pose6d).view(B, 24, 3, 3)
+    x, fmt = regressor.prepare_input(proxy_rep)
+    r = rt.get(x.device)
+    B = x.shape[0]
+    smpl.to(r.device)
+    if B > smpl.max_batch:
+        raise ValueError(f'reconstruct_players: batch {B} exceeds the SMPL handle\'s max_batch {smpl.max_batch}')
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=r.device)
+    cam, pose6d, betas, R = f32(B, 3), f32(B, 144), f32(B, 10), f32(B, 24, 3, 3)
+    vertices, joints, translation = f32(B, 6890, 3), f32(B, 90, 3), f32(B, 3)
+    out = _abi.PipelineOut(cam=rt.ptr(cam).value, pose6d=rt.ptr(pose6d).value, betas=rt.ptr(betas).value, rotmats=rt.ptr(R).value,
+                           vertices=rt.ptr(vertices).value, joints=rt.ptr(joints).value, translation=rt.ptr(translation).value)
+    rel_handle = bx = None
     if pose_relation is not None:       # `use_relate`, PR/PyTorch3DTest.py:3758-3759: the batch is ONE frame's players
         if boxes is None:
             raise ValueError('reconstruct_players: pose_relation needs boxes= [B,4] (x_min, y_min, x_max, y_max)')
-        R = pose_relation([R, boxes])
+        pose_relation.to(r.device)
+        if B > pose_relation.max_players:
+            raise ValueError(f'reconstruct_players: {B} players exceed the relation module\'s max_players')
+        bx = rt.dev_f32(torch.as_tensor(boxes), r.device).reshape(B, 4).contiguous()
+        tmp = f32(B, 216)
+        out.relate_tmp = rt.ptr(tmp).value
+        rel_handle = pose_relation.handle
+    cfg = j2d = None
     if fit is not None:
         variant = {'camera': 0, 'pose_shape': 1}[fit]
-        fit_players(smpl, R, betas, cam, joints2D, variant=variant, iters=iters, lr=lr, select_mode=select_mode)
-    out = smpl(full_pose=R, betas=betas, pose2rot=False)
-    res = SimpleNamespace(cam=cam, rotmats=R, betas=betas, vertices=out.vertices, joints=out.joints,
-                          translation=convert_weak_perspective_to_camera_translation_torch(
-                              cam, config.FOCAL_LENGTH, config.proxy_rep_input_wh))
+        cfg = _fit_config(r, variant, iters, lr, None, select_mode)
+        j2d = rt.dev_f32(torch.as_tensor(joints2D)[..., :2], r.device).reshape(B, 17, 2).contiguous()
+    # one C call issues the whole chain of launches (csrc/pipeline.hip)
+    r.check(r.lib.spsp_pipeline(r.ctx, regressor.handle, smpl.handle, rel_handle, rt.ptr(x), fmt, rt.ptr(bx), rt.ptr(j2d),
+                                C.byref(cfg) if cfg is not None else None, B, config.FOCAL_LENGTH,
+                                config.proxy_rep_input_wh, C.byref(out), r.stream()), 'spsp_pipeline')
+    res = SimpleNamespace(cam=cam, rotmats=R, betas=betas, vertices=vertices, joints=joints, translation=translation,
+                          pose6d=pose6d)
     if return_vertices2d:   # PR/PyTorch3DTest.py:3774-3776
-        res.vertices2d = orthographic_project_to_pixels(out.vertices, cam, config.proxy_rep_input_wh)
+        res.vertices2d = orthographic_project_to_pixels(vertices, cam, config.proxy_rep_input_wh)
     return res
 
 
