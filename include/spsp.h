@@ -220,6 +220,19 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant /* 0 = A camera, 1 
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream);
 
+/* ---- exchange step without torch: ONE RCCL all-gather of the packed records over xGMI, for hosts that
+ *      drive this library directly.  Rank 0 calls spsp_comm_unique_id and ships the 128 bytes to the other ranks
+ *      (any channel); every rank calls spsp_comm_init_rank on its own device; spsp_allgather_records gathers
+ *      n_per_rank records of every rank into all [nranks * n_per_rank, 229] in rank order, asynchronously on `stream`
+ *      (ragged frames: pad the last shards, as soccerplayershapepose_amd.sharding does).  RCCL is resolved at run
+ *      time; inside a PyTorch process the Python mirror uses torch.distributed for the same collective. */
+typedef struct spsp_comm spsp_comm;
+int  spsp_comm_unique_id(void* id128 /* host, 128 bytes */);
+int  spsp_comm_init_rank(spsp_ctx* ctx, const void* id128, int nranks, int rank, spsp_comm** out);
+void spsp_comm_destroy(spsp_comm* comm);
+int  spsp_allgather_records(spsp_ctx* ctx, spsp_comm* comm, const float* local /* [n_per_rank,229] */, int n_per_rank,
+                            float* all /* [nranks*n_per_rank,229] */, void* stream);
+
 /* ---- the whole path in one call: the core of evaluate_model_2d (PR/PyTorch3DTest.py:3738-3776) ----------------
  * proxy -> regressor -> rot6d -> [relation module, if `relate`] -> [fit, if `fit`] -> SMPL forward -> translation
  * [-> packed record].  Issues the stage launches in order on `stream`; every buffer is a caller-owned device

@@ -20,6 +20,7 @@ FIT_BETAS = 1 << 25
 FIT_MASK_CAMERA = FIT_GLOBAL_ORIENT | FIT_CAM
 FIT_MASK_POSE_SHAPE = FIT_GLOBAL_ORIENT | FIT_CAM | FIT_BETAS | 0x003FFE7E
 FIT_SELECT_LAST, FIT_SELECT_BEST_L2E = 0, 1
+OK, EINVAL, ENOMEM, EHIP, ENCCL = 0, -1, -2, -3, -4           # include/spsp.h status codes
 PROXY_NCHW_F32, PROXY_NATIVE = 0, 1
 PRECISION_BF16, PRECISION_F16 = 0, 1
 SIL_U8, SIL_F32 = 0, 1
@@ -114,6 +115,10 @@ _PROTOS = {
     'spsp_regressor_free': (None, [_vp]),
     'spsp_proxy_native_bytes': (C.c_size_t, []),
     'spsp_proxy_pack': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'spsp_comm_unique_id': (C.c_int, [_vp]),
+    'spsp_comm_init_rank': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    'spsp_comm_destroy': (None, [_vp]),
+    'spsp_allgather_records': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     'spsp_pipeline': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.POINTER(FitConfig), C.c_int, C.c_float,
                                C.c_float, C.POINTER(PipelineOut), _vp]),
     'spsp_relate_load': (C.c_int, [_vp, C.POINTER(RelateWeights), C.c_int, C.POINTER(_vp)]),
@@ -158,6 +163,6 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().spsp_last_error().decode('utf-8', 'replace')
-        if rc == -1:
+        if rc == EINVAL:
             raise ValueError(f'{what}: {msg}')
         raise RuntimeError(f'{what} failed (status {rc}): {msg}')

@@ -589,3 +589,34 @@ def test_pose_relation_module_against_reference_golden_and_oracle(regressor_gpu,
     assert torch.equal(res.rotmats, R2) and torch.equal(res.vertices, smpl_gpu(full_pose=R2, betas=shape).vertices)
     with pytest.raises(ValueError):
         reconstruct_players(regressor_gpu, smpl_gpu, xt, None, fit=None, pose_relation=rel)
+
+
+# ---------------------------------------------------------------- exchange step through the C ABI (8e)
+def test_c_abi_rccl_allgather_of_records_single_rank(dev):
+    """spsp_comm_* / spsp_allgather_records: the torch-free form of the one collective on the path.  A one-GPU box
+    can only form a 1-rank communicator; that still goes through ncclCommInitRank + ncclAllGather on the stream.
+    Run in a child process so RCCL is initialised by this library alone (no torch.distributed in the process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, torch
+        from soccerplayershapepose_amd import _abi, runtime as rt
+        dev = torch.device('cuda', 0)
+        r = rt.get(dev)
+        uid = (C.c_char * 128)()
+        r.check(r.lib.spsp_comm_unique_id(uid), 'uid')
+        comm = C.c_void_p()
+        r.check(r.lib.spsp_comm_init_rank(r.ctx, uid, 1, 0, C.byref(comm)), 'init')
+        local = torch.arange(22 * 229, dtype=torch.float32, device=dev).reshape(22, 229) / 7
+        out = torch.full((22, 229), -1.0, device=dev)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            r.check(r.lib.spsp_allgather_records(r.ctx, comm, rt.ptr(local), 22, rt.ptr(out), r.stream()), 'allgather')
+        st.synchronize()
+        assert torch.equal(out, local)
+        assert r.lib.spsp_comm_init_rank(r.ctx, uid, 2, 5, C.byref(C.c_void_p())) == _abi.EINVAL
+        r.lib.spsp_comm_destroy(comm)
+        print('rccl-ok')
+    """)
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'rccl-ok' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
