@@ -114,3 +114,37 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f'{f} imports the oracle'
+
+
+def test_public_header_is_valid_c99_and_a_c_host_links_against_the_library(tmp_path):
+    """include/spsp.h is the contract of the drop-in boundary: it must compile as plain C (no C++-isms, no torch
+    types), and a C host must link against libspsp.so and reach the GPU-free entry points."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'soccerplayershapepose_amd', 'csrc')
+    src = tmp_path / 'host.c'
+    src.write_text('''
+        #include <stdio.h>
+        #include <string.h>
+        #include "spsp.h"
+        int main(void) {
+            spsp_fit_config a, b;
+            spsp_fit_config_default(&a, 0);
+            spsp_fit_config_default(&b, 1);
+            if (a.iters != 50 || b.iters != 50 || a.lr != 0.01 || b.lr != 0.001) return 2;
+            if (a.param_mask != SPSP_FIT_MASK_CAMERA || b.param_mask != SPSP_FIT_MASK_POSE_SHAPE) return 3;
+            if (spsp_proxy_native_bytes() != (size_t)SPSP_PROXY_NATIVE_H * SPSP_PROXY_NATIVE_W * 18 * 2) return 4;
+            if (strncmp(spsp_version(), "spsp", 4) != 0 || spsp_profile_num_kernels() < 10) return 5;
+            if (spsp_regressor_forward(NULL, NULL, NULL, 0, 1, NULL, NULL, NULL, NULL, NULL) != SPSP_EINVAL) return 6;
+            printf("%s|%s\\n", spsp_version(), spsp_last_error());
+            return 0;
+        }''')
+    exe = tmp_path / 'host'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', f'-I{os.path.join(root, "include")}',
+                           str(src), '-o', str(exe), f'-L{lib_dir}', '-lspsp', f'-Wl,-rpath,{lib_dir}'])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.startswith('spsp') and 'NULL handle' in out.stdout
