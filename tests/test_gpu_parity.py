@@ -620,3 +620,30 @@ def test_c_abi_rccl_allgather_of_records_single_rank(dev):
     """)
     p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and 'rccl-ok' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_handles_release_their_device_memory(regressor_sd_np, smpl_model_np, dev):
+    """Loading and dropping handles repeatedly must give all device memory back (DevicePool frees on destroy)."""
+    import gc
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    from soccerplayershapepose_amd.models.smpl_official import SMPL
+    from soccerplayershapepose_amd.models.regressor_relate import PoseRelationModule
+
+    def cycle():
+        reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=16).load_state_dict(regressor_sd_np).to(dev)
+        smpl = SMPL(smpl_model_np, max_batch=16).to(dev)
+        rel = PoseRelationModule(max_players=16).load_state_dict(S.relation_state_dict(seed=0)).to(dev)
+        x, _ = S.proxy_crops(2, seed=3)
+        cam, pose, shape = reg(torch.from_numpy(x).to(dev))
+        torch.cuda.synchronize()
+        del reg, smpl, rel, cam, pose, shape
+        gc.collect()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 < 8 << 20, f'{(free0 - free1) / 2**20:.1f} MiB not returned after 6 load/free cycles'
