@@ -43,6 +43,8 @@ int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 // third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 px x 64 ch per workgroup
 bool conv_patch_supported(const ConvArgs& a);
 int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream);
+// second pass of a split-K convolution (a.splitk slabs in a.part): sum + bias (+ residual) + ReLU -> out (+ avg-pool)
+int launch_splitk_epilogue(const ConvArgs& a, hipStream_t stream);
 
 // conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
 bool conv_wres_supported(const ConvArgs& a);

@@ -101,7 +101,11 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         const int t = m_tile - img0 * tpi;
         y0 = (t / tpr) * 16; x0 = (t % tpr) * 16;
     }
-    const int nchunks = a.chunks;                                  // Cin / 64
+    // split-K over workgroups (deep, tile-starved layers): blockIdx.y takes chunks [ch0, ch0 + nchunks) of a.chunks and
+    // leaves its fp32 partial tile in slab blockIdx.y of a.part; splitk_epilogue_kernel (conv_ring.hip) finishes.
+    const int nch_tot = a.chunks;                                  // Cin / 64
+    const int nchunks = a.splitk > 1 ? nch_tot / a.splitk : nch_tot;
+    const int ch0 = a.splitk > 1 ? (int)blockIdx.y * nchunks : 0;
     const uint16_t* const in_ptr = a.in;                           // scalar copies (keep the kernarg struct out of lambdas)
     const uint16_t* const w_ptr = a.w;
     const int Ktot = a.nsteps * 64;                                // 9 * Cin
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < G::DPW; ++i) {
             const int p = wave_id + NW * i;
-            if (p < G::NDMA) dma16(in_ptr + p_src[i] + ch * 64, patch0 + p * 1024);
+            if (p < G::NDMA) dma16(in_ptr + p_src[i] + (ch0 + ch) * 64, patch0 + p * 1024);
         }
     };
     // ---- weight ring sources: stage = [64 n][64 k] of K-step g (tap-major, chunk-minor: g = tap*nchunks + ch) ----
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         auto issue_group = [&](int g) {
             const int gch = g / 3, gr = g - gch * 3;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nchunks + gch, (g & 1) * 3 + t);
+            for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nch_tot + ch0 + gch, (g & 1) * 3 + t);
         };
         issue_group(0);
 #define SPSP_GTAP(TAP, SET, SLOT, FIRST)                                                                  \
@@ -270,11 +274,11 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 #undef SPSP_GTAP
     } else {
     int issued = 0;
-    for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w((issued % 9) * nchunks + issued / 9, issued);
+    for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w((issued % 9) * nch_tot + ch0 + issued / 9, issued);
     auto issue_next = [&]() {
         if (issued < nsteps) {
             const int ich = issued / 9, itap = issued - ich * 9;
-            issue_w(itap * nchunks + ich, issued % kNS);
+            issue_w(itap * nch_tot + ch0 + ich, issued % kNS);
             ++issued;
         }
     };
@@ -359,6 +363,26 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     //   E  output tile    LDS -> global   (16 B per lane, whole lines)
     // LDS tiles are [256 px][128 B] with the 16-byte chunk XOR-swizzled by the pixel (bank-conflict-free both ways).
     // tile pixel tp = wave*64 + j*16 + frow.
+    if (a.splitk > 1) {
+        // partial tile -> slab [blockIdx.y][m][n] (m = linear pixel index); a lane's 4 channels are one 16-byte store
+        float* const slab = a.part + (size_t)blockIdx.y * a.M * a.N;
+        auto put_slab = [&](auto I0c) {
+            constexpr int I0 = decltype(I0c)::value, NI = 4 / KS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tp = wave * 64 + j * 16 + frow;
+                size_t m;
+                if constexpr (W8) m = (size_t)m_tile * 256 + tp;
+                else m = ((size_t)img0 * W + (y0 + (tp >> 4))) * W + (x0 + (tp & 15));
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    *reinterpret_cast<f32x4*>(slab + m * a.N + n_blk + (I0 + i) * 16 + fq * 4) = acc[I0 + i][j];
+            }
+        };
+        if constexpr (KS == 1) put_slab(std::integral_constant<int, 0>{});
+        else { if (kw == 0) put_slab(std::integral_constant<int, 0>{}); else put_slab(std::integral_constant<int, 2>{}); }
+        return;
+    }
     __syncthreads();                                   // ring / patch / exchange buffers are dead from here on
     unsigned char* const resT = smem;
     unsigned char* const outT = smem + 256 * 128;
@@ -455,7 +479,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    conv3x3_patch_kernel<W8, KS, NS, F16><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(a);
+    conv3x3_patch_kernel<W8, KS, NS, F16><<<dim3((a.M / 256) * (a.N / 64), a.splitk > 1 ? a.splitk : 1), 256 * KS, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
@@ -471,7 +495,7 @@ namespace spsp {
 
 bool conv_patch_supported(const ConvArgs& a) {
     return a.stride == 1 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && a.in_off == 0 && a.M % 256 == 0 && a.N % 64 == 0 &&
-           a.Ho == a.Wo && (a.Wo == 8 || a.Wo % 16 == 0) && a.splitk <= 1;
+           a.Ho == a.Wo && (a.Wo == 8 || a.Wo % 16 == 0) && (a.splitk <= 1 || (a.part && a.chunks % a.splitk == 0));
 }
 
 int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream) {

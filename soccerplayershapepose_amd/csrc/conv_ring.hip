@@ -303,6 +303,19 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 namespace spsp {
 
+int launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
+    SPSP_REQUIRE(a.splitk > 1 && a.part, "splitk_epilogue: no slabs");
+    const size_t total = (size_t)a.M * (a.N / 4);
+    if (a.f16) splitk_epilogue_kernel<true><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+    else splitk_epilogue_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+    SPSP_HIP_CHECK(hipGetLastError());
+    if (a.pool_out) {
+        pool_from_slab_kernel<<<a.M / (a.Ho * a.Wo), 256, 0, st>>>(a.part, a.Ho * a.Wo, a.N, a.pool_out);
+        SPSP_HIP_CHECK(hipGetLastError());
+    }
+    return SPSP_OK;
+}
+
 int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream) {
     switch (tile) {
         case kRing128x128s3: return launch<128, 128, 3>(a, stream);

@@ -213,6 +213,7 @@ struct spsp_regressor {
     bool use_patch;        // 3x3 stride-1 convs through conv_patch.hip
     bool conv1_patch;      // stem through conv1_patch.hip
     bool use_wres;         // layer1 through conv_wres.hip
+    int patch_splitk[4];   // split-K factor of the patch kernel per stage (deep stages have fewer tiles than CUs at 32 crops)
     int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs), 3: 1 + grouped ring
 };
 
@@ -251,8 +252,13 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
         const int v = r->patch_variant[L];
         const int kid3 = a.Wo == 8 ? (v == 3 ? kKPatchW8Grp : v ? kKPatchW8Big : kKPatchW8Small)
                                    : (v == 3 ? kKPatchW16Grp : v ? kKPatchW16Big : kKPatchW16Small);
+        int sk = r->patch_splitk[L];
+        while (sk > 1 && (a.chunks % sk != 0 || (size_t)sk * a.M * a.N > r->slab_floats)) sk >>= 1;
+        if (sk > 1) { a.splitk = sk; a.part = r->slab; }
         ProfScope ps(ctx, kid3, st);
-        return launch_conv_patch(a, v, st);
+        const int rc = launch_conv_patch(a, v, st);
+        if (rc != SPSP_OK || sk <= 1) return rc;
+        return launch_splitk_epilogue(a, st);
     }
     if (L >= 0 && r->ring[L] != kRingNone) {
         const RingTile rt = r->ring[L];
@@ -352,6 +358,9 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         if (const char* pe = getenv("SPSP_CONV1_PATCH")) r->conv1_patch = atoi(pe) != 0;
         const int def_v[4] = {3, 3, 3, 3};   // measured at 32 crops: 8 waves + grouped ring (one barrier per kernel row) wins on every stage
         for (int L = 0; L < 4; ++L) r->patch_variant[L] = def_v[L];
+        for (int L = 0; L < 4; ++L) r->patch_splitk[L] = 1;
+        if (const char* ps = getenv("SPSP_PATCH_SPLITK"))      // e.g. "1124"
+            for (int L = 0; L < 4 && ps[L]; ++L) r->patch_splitk[L] = ps[L] - '0';
         if (const char* pv = getenv("SPSP_PATCH_VARIANT"))       // e.g. "0111"
             for (int L = 0; L < 4 && pv[L]; ++L) r->patch_variant[L] = pv[L] - '0';
         if (const char* env = getenv("SPSP_CONV_PLAN")) {
