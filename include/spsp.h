@@ -70,6 +70,10 @@ int         spsp_profile_select(spsp_ctx* ctx, int kernel_id);
 int         spsp_profile_num_kernels(void);
 const char* spsp_profile_kernel_name(int id);
 int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);
+/* Instead of the sums: one (kernel id, stream, start, stop) record per bracketed launch site, times in ms relative to the
+ * first record; clears the records.  For timeline studies of the multi-stream pipeline (tools/timeline.py). */
+int         spsp_profile_timeline(spsp_ctx* ctx, int max_records, int* ids, unsigned long long* streams, double* start_ms,
+                                  double* stop_ms, int* count);
 
 /* ---- relation module: replaces PoseRelationModule (PR/models/regressor_relate.py:9-139; used between rot6d and
  *      the fit at PR/PyTorch3DTest.py:3758-3759 when use_relate) -- the players of ONE frame attend to each other.

@@ -93,7 +93,7 @@ enum KernelId {
     kKConvIgemm,       // conv_igemm_kernel<...> (first generation, fallbacks)
     kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate, kKNumKernels
 };
-struct ProfRec { int id; hipEvent_t start, stop; };
+struct ProfRec { int id; hipEvent_t start, stop; hipStream_t stream; };
 }  // namespace spsp
 
 struct spsp_ctx {
@@ -118,7 +118,7 @@ struct ProfScope {
         }
         (void)hipEventRecord(ev[0], st);
         stop = ev[1];
-        c->prof_recs.push_back({id, ev[0], ev[1]});
+        c->prof_recs.push_back({id, ev[0], ev[1], st});
     }
     ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
 };

@@ -62,6 +62,27 @@ int spsp_profile_select(spsp_ctx* ctx, int kernel_id) {
     return SPSP_OK;
 }
 
+int spsp_profile_timeline(spsp_ctx* ctx, int max_records, int* ids, unsigned long long* streams, double* start_ms,
+                          double* stop_ms, int* count) {
+    SPSP_REQUIRE(ctx && ids && streams && start_ms && stop_ms && count && max_records >= 0, "spsp_profile_timeline: bad arguments");
+    int n = 0;
+    for (auto& r : ctx->prof_recs) {
+        SPSP_HIP_CHECK(hipEventSynchronize(r.stop));
+        if (n < max_records) {
+            float a = 0.f, b = 0.f;
+            SPSP_HIP_CHECK(hipEventElapsedTime(&a, ctx->prof_recs.front().start, r.start));
+            SPSP_HIP_CHECK(hipEventElapsedTime(&b, ctx->prof_recs.front().start, r.stop));
+            ids[n] = r.id; streams[n] = (unsigned long long)(uintptr_t)r.stream; start_ms[n] = a; stop_ms[n] = b;
+            ++n;
+        }
+        ctx->prof_free.push_back(r.start);
+        ctx->prof_free.push_back(r.stop);
+    }
+    ctx->prof_recs.clear();
+    *count = n;
+    return SPSP_OK;
+}
+
 int spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches) {
     SPSP_REQUIRE(ctx && total_ms && launches && n >= spsp::kKNumKernels, "spsp_profile_read: need %d slots", spsp::kKNumKernels);
     for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
