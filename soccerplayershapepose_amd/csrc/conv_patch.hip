@@ -10,8 +10,12 @@
 // L2 -> LDS bytes per MFMA cycle drop from 64-128 (implicit GEMM, 128x128..64x64 tiles) to ~16 (weights) + ~10
 // (patch), inside what one CU can pull from L2.
 //
-// Patch image: pixel-major [pixels][64 ch] bf16, 128 B per pixel, 16-byte chunk index XOR-swizzled by
-// f(q) = (q >> 1) & 7 of the patch pixel index q.  It is written by LDS-DMA (lane-linear: 8 pixels x 8 chunks per
+// Patch image: pixel-major [pixels][64 ch] bf16, 128 B per pixel, 16-byte chunk index XOR-swizzled by f(q) of the patch
+// pixel index q: f = q & 7 for the 16-pixel-row tiles -- conflict-free for ds_read_b128, whose four lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... each touch 16 DISTINCT 16-byte bank slots ((a / 16) mod 16) for any
+// 16 consecutive pixels (the first version used (q >> 1) & 7: 2-way conflicts at 3 of 4 tap positions, 8 LDS cycles
+// per fragment read instead of 4; model: tools/lds_bank_check.py).  The 8 x 8-map tiles (two 8-pixel rows per
+// fragment) keep (q >> 1) & 7: no linear swizzle is conflict-free for that shape.  It is written by LDS-DMA (lane-linear: 8 pixels x 8 chunks per
 // wave-instruction, swizzle applied on the SOURCE chunk) and read with ds_read_b128; the swizzle of the shifted
 // pixel q + tap is recomputed per tap with 4 VALU ops that hide under the MFMAs.
 //
@@ -61,6 +65,9 @@ constexpr int kWStage = 64 * 128;            // [64 n][64 k] bf16
 #define CSTAMP(i)
 #endif
 constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
+
+template <bool W8>
+__device__ __forceinline__ int patch_swz(int q) { return W8 ? ((q >> 1) & 7) : (q & 7); }
 
 template <bool W8, int KS, int NS>
 struct Geo {
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
             const int py = q / 18, px = q - py * 18;
             off = img0 * a.in_img + (y0 + py) * a.in_row + (x0 + px) * a.in_pix;
         }
-        p_src[i] = off + ((dchunk ^ ((q >> 1) & 7)) * 8);
+        p_src[i] = off + ((dchunk ^ patch_swz<W8>(q)) * 8);
     }
     auto issue_patch = [&](int ch) {
 #pragma unroll
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = qb + j * QJ + (tap / 3) * PW + (tap % 3);
-            xoff[tap][j] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ ((q >> 1) & 7)) * 16);
+            xoff[tap][j] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
         }
 
     // K order inside the kernel: chunk-major, tap-minor (patch of chunk ch serves 9 consecutive steps); the weight

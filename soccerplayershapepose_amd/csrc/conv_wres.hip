@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         int q = (wave + 4 * i) * 8 + drow;
         q = q < kNPix ? q : kNPix - 1;
         const int py = q / 18, px = q - py * 18;
-        p_rel[i] = py * a.in_row + px * a.in_pix + ((dchunk ^ ((q >> 1) & 7)) * 8);
+        p_rel[i] = py * a.in_row + px * a.in_pix + ((dchunk ^ (q & 7)) * 8);        // chunk swizzle q & 7: conflict-free ds_read_b128 (see conv_patch.hip)
     }
     auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
         img = t / tpi;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = qb + j * 18 + (tap / 3) * 18 + (tap % 3);
-            xoff[tap][j] = smem_base + kWAll + q * 128 + ((fq ^ ((q >> 1) & 7)) * 16);
+            xoff[tap][j] = smem_base + kWAll + q * 128 + ((fq ^ (q & 7)) * 16);
         }
 
     // bias of this lane's 4 x 4 channels, once
