@@ -135,11 +135,11 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         }
         p_src[i] = off + ((dchunk ^ patch_swz<W8>(q)) * 8);
     }
-    auto issue_patch = [&](int ch) {
+    auto issue_patch = [&](int ch, int pbuf = 0) {
 #pragma unroll
         for (int i = 0; i < G::DPW; ++i) {
             const int p = wave_id + NW * i;
-            if (p < G::NDMA) dma16(in_ptr + p_src[i] + (ch0 + ch) * 64, patch0 + p * 1024);
+            if (p < G::NDMA) dma16(in_ptr + p_src[i] + (ch0 + ch) * 64, patch0 + pbuf * G::PATCH + p * 1024);
         }
     };
     // ---- weight ring sources: stage = [64 n][64 k] of K-step g (tap-major, chunk-minor: g = tap*nchunks + ch) ----
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
             wfr[SET][kk][2] = lds_read_b128<4096>(wa_);                                                   \
             wfr[SET][kk][3] = lds_read_b128<6144>(wa_);                                                   \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
-                xfr[SET][kk][j] = lds_read_b128<0>(KS == 2 ? xoff[TAP][j] : (xoff[TAP][j] ^ (kk * 64)));  \
+                xfr[SET][kk][j] = lds_read_b128<0>((KS == 2 ? xoff[TAP][j] : (xoff[TAP][j] ^ (kk * 64))) + pboff_); \
         }                                                                                                 \
     }
 #define SPSP_MFMA_SET(SET)                                                                                \
@@ -254,21 +254,14 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 #define SPSP_GROUP(R, P0, CH, HALF)                                                                       \
     {                                                                                                     \
         const int g_ = (CH) * 3 + (R);                                                                    \
+        const uint32_t pboff_ = ((CH) & 1) * G::PATCH;          /* this chunk's patch buffer */            \
         wait_vmcnt<0>();                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                     \
-        if ((R) == 0 && (CH) > 0) {                                                                       \
-            /* chunk boundary: every wave is past its last read of the old patch; refill it, run the pending */ \
-            /* MFMAs of the previous tap underneath, then wait for the patch (older than the slabs issued next) */ \
-            issue_patch(CH);                                                                              \
-            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
-            SPSP_MFMA_SET(((P0) & 1) ^ 1)                                                                 \
-            if (g_ + 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
-            __builtin_amdgcn_s_barrier();                                                                 \
-            SPSP_GTAP(0, (P0) & 1, (HALF) * 3 + 0, true)                                                  \
-        } else {                                                                                          \
-            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
-            SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (HALF) * 3 + 0, (R) == 0 && (CH) == 0)       \
-        }                                                                                                 \
+        /* first group of a chunk: every wave is past its reads of chunk CH-1, whose patch buffer now takes */ \
+        /* chunk CH+1 -- it has the nine taps of this chunk to land (no exposed wait at chunk boundaries)    */ \
+        if ((R) == 0 && (CH) + 1 < nchunks) issue_patch((CH) + 1, ((CH) + 1) & 1);                        \
+        if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                        \
+        SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (HALF) * 3 + 0, (R) == 0 && (CH) == 0)           \
         SPSP_GTAP((R) * 3 + 1, ((R) * 3 + 1 + (P0)) & 1, (HALF) * 3 + 1, false)                           \
         SPSP_GTAP((R) * 3 + 2, ((R) * 3 + 2 + (P0)) & 1, (HALF) * 3 + 2, false)                           \
     }
@@ -280,6 +273,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 #undef SPSP_GROUP
 #undef SPSP_GTAP
     } else {
+    constexpr uint32_t pboff_ = 0;
     int issued = 0;
     for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w((issued % 9) * nch_tot + ch0 + issued / 9, issued);
     auto issue_next = [&]() {
@@ -464,7 +458,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 template <bool W8, int KS, int NS, bool F16>
 int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, KS, NS>;
-    constexpr size_t lds = (size_t)NS * kWStage + G::PATCH;
+    constexpr size_t lds = (size_t)NS * kWStage + (NS == 6 ? 2 : 1) * G::PATCH;
     static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
     static bool set = false;
     if (!set) {
