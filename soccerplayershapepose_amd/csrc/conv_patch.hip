@@ -4,7 +4,7 @@
 // 3x3 conv pulls 9x its input through the L2 -> LDS path, and that path (not HBM: the L2 hit rate is ~85 %, not
 // MFMA) is what they saturate at 32 crops.  Here a workgroup loads the (tile + halo) pixels of one 64-channel
 // chunk ONCE, keeps them in LDS, and feeds all 9 taps from there; only the [64 x 64] weight slab of each tap is
-// streamed (4-stage LDS-DMA ring).  Per workgroup: 256 output pixels x 64 output channels, 4 waves of 64 x 64,
+// streamed (LDS-DMA ring).  Per workgroup: 256 output pixels x 64 output channels, wave tile 64 x 64,
 // v_mfma_f32_16x16x32_bf16, weights = A operand, pixels = B operand (lane = pixel -> 8-byte NHWC stores).
 //
 // L2 -> LDS bytes per MFMA cycle drop from 64-128 (implicit GEMM, 128x128..64x64 tiles) to ~16 (weights) + ~10
@@ -15,20 +15,26 @@
 // {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... each touch 16 DISTINCT 16-byte bank slots ((a / 16) mod 16) for any
 // 16 consecutive pixels (the first version used (q >> 1) & 7: 2-way conflicts at 3 of 4 tap positions, 8 LDS cycles
 // per fragment read instead of 4; model: tools/lds_bank_check.py).  The 8 x 8-map tiles (two 8-pixel rows per
-// fragment) keep (q >> 1) & 7: no linear swizzle is conflict-free for that shape.  It is written by LDS-DMA (lane-linear: 8 pixels x 8 chunks per
-// wave-instruction, swizzle applied on the SOURCE chunk) and read with ds_read_b128; the swizzle of the shifted
-// pixel q + tap is recomputed per tap with 4 VALU ops that hide under the MFMAs.
+// fragment) keep (q >> 1) & 7: no linear swizzle is conflict-free for that shape.
+// The image is written by LDS-DMA (lane-linear: 8 pixels x 8 chunks per wave-instruction, swizzle applied on the
+// SOURCE chunk) and read with ds_read_b128; the 36 per-lane fragment offsets (9 taps x 4 tiles) live in registers.
 //
 // Tile geometries (W = feature-map width = height):
 //   W >= 16 : tile = 16 x 16 pixels of one image, patch 18 x 18; wave w owns rows 4w..4w+3, MFMA tile j = one row.
 //   W == 8  : tile = 4 whole 8 x 8 images, patch 4 x (10 x 10); wave w owns image w, MFMA tile j = rows 2j, 2j+1.
 //
-// Occupancy: ONE patch buffer + a 3-stage weight ring = 65-74 KB of LDS and <= 256 registers per lane, so two
-// workgroups share a CU (two waves per SIMD): while one wave runs its 32 MFMAs of a tap the other does its
-// LDS reads / DMA issue / epilogue.  (Measured on the first version, one wave per SIMD: 29 % MFMA-busy in layer4,
-// the rest was this wave's own VALU + LDS latency + barriers, serialised in front of its MFMAs.)  The patch of
-// the next 64-channel chunk can therefore only be fetched after the last tap of the current one; the partner
-// workgroup covers that bubble.
+// Variants (template <W8, KS, NS>; regressor.hip picks per stage, SPSP_PATCH_VARIANT overrides):
+//   <., 1, 3>  4 waves, per-tap ring of 3 slabs, one patch buffer: 65-74 KB, two workgroups per CU.  The first form;
+//              at 32 crops a layer has no more tiles than the chip has CUs, so the partner workgroup rarely exists.
+//   <., 2, 5>  8 waves: wave pairs (w, w+4 -- the two waves of one SIMD) split every K-step in halves and exchange
+//              accumulators through LDS at the end; per-tap ring of 5 slabs.
+//   <., 2, 6>  (default) as above with a GROUPED ring -- the three slabs of a kernel row land together in one half
+//              of a 2 x 3-slab ring, one vmcnt(0) + barrier per three taps -- and TWO patch buffers, so the next
+//              64-channel chunk's patch lands under the nine taps of the current one (131 / 150 KB of LDS).
+// Fragment reads are software-pipelined one tap ahead of the MFMAs in every variant (two register sets).
+// What the counters say about <false, 2, 6> alone on the chip (rocprofv3 --pmc, layer2 shape): the matrix pipe is busy
+// 25 % of the kernel; a wave is parked in s_waitcnt / s_barrier 46 % of its cycles, stalled at issue (matrix pipe taken
+// by its SIMD partner, MFMA dependencies) 33 %, issuing 21 %; LDS bank conflicts < 5 % of LDS cycles.
 #include <cstdlib>
 #include <type_traits>
 
