@@ -29,8 +29,9 @@
 //   <., 2, 5>  8 waves: wave pairs (w, w+4 -- the two waves of one SIMD) split every K-step in halves and exchange
 //              accumulators through LDS at the end; per-tap ring of 5 slabs.
 //   <., 2, 6>  (default) as above with a GROUPED ring -- the three slabs of a kernel row land together in one half
-//              of a 2 x 3-slab ring, one vmcnt(0) + barrier per three taps -- and TWO patch buffers, so the next
-//              64-channel chunk's patch lands under the nine taps of the current one (131 / 150 KB of LDS).
+//              of a 2 x 3-slab ring, one vmcnt(0) + barrier per three taps; with DB (template flag, the default for
+//              layer3 / layer4) TWO patch buffers, so the next 64-channel chunk's patch lands under the nine taps of
+//              the current one (131 / 150 KB of LDS instead of 89 / 99 KB).
 // Fragment reads are software-pipelined one tap ahead of the MFMAs in every variant (two register sets).
 // What the counters say about <false, 2, 6> alone on the chip (rocprofv3 --pmc, layer2 shape): the matrix pipe is busy
 // 25 % of the kernel; a wave is parked in s_waitcnt / s_barrier 46 % of its cycles, stalled at issue (matrix pipe taken
@@ -86,7 +87,7 @@ struct Geo {
 };
 
 // One workgroup: 256 pixels x 64 channels.  grid = (M/256) * (N/64) (XCD-contiguous order).
-template <bool W8, int KS, int NS, bool F16>
+template <bool W8, int KS, int NS, bool F16, bool DB>
 __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs a) {
     using G = Geo<W8, KS, NS>;
     constexpr int PW = G::PW, kNS = NS, NW = G::NW;
@@ -260,14 +261,25 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
 #define SPSP_GROUP(R, P0, CH, HALF)                                                                       \
     {                                                                                                     \
         const int g_ = (CH) * 3 + (R);                                                                    \
-        const uint32_t pboff_ = ((CH) & 1) * G::PATCH;          /* this chunk's patch buffer */            \
+        const uint32_t pboff_ = DB ? ((CH) & 1) * G::PATCH : 0;   /* this chunk's patch buffer */          \
         wait_vmcnt<0>();                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                     \
-        /* first group of a chunk: every wave is past its reads of chunk CH-1, whose patch buffer now takes */ \
-        /* chunk CH+1 -- it has the nine taps of this chunk to land (no exposed wait at chunk boundaries)    */ \
-        if ((R) == 0 && (CH) + 1 < nchunks) issue_patch((CH) + 1, ((CH) + 1) & 1);                        \
-        if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                        \
-        SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (HALF) * 3 + 0, (R) == 0 && (CH) == 0)           \
+        if (!DB && (R) == 0 && (CH) > 0) {                                                                \
+            /* one patch buffer, chunk boundary: every wave is past its last read of the old patch; refill it, run */ \
+            /* the pending MFMAs of the previous tap underneath, then wait for the patch (older than the slabs) */ \
+            issue_patch(CH);                                                                              \
+            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
+            SPSP_MFMA_SET(((P0) & 1) ^ 1)                                                                 \
+            if (g_ + 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
+            __builtin_amdgcn_s_barrier();                                                                 \
+            SPSP_GTAP(0, (P0) & 1, (HALF) * 3 + 0, true)                                                  \
+        } else {                                                                                          \
+            /* two patch buffers, first group of a chunk: every wave is past its reads of chunk CH-1, whose buffer */ \
+            /* now takes chunk CH+1 -- it has the nine taps of this chunk to land (no wait at chunk boundaries)    */ \
+            if (DB && (R) == 0 && (CH) + 1 < nchunks) issue_patch((CH) + 1, ((CH) + 1) & 1);              \
+            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
+            SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (HALF) * 3 + 0, (R) == 0 && (CH) == 0)       \
+        }                                                                                                 \
         SPSP_GTAP((R) * 3 + 1, ((R) * 3 + 1 + (P0)) & 1, (HALF) * 3 + 1, false)                           \
         SPSP_GTAP((R) * 3 + 2, ((R) * 3 + 2 + (P0)) & 1, (HALF) * 3 + 2, false)                           \
     }
@@ -461,14 +473,14 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     CSTAMP(6);
 }
 
-template <bool W8, int KS, int NS, bool F16>
+template <bool W8, int KS, int NS, bool F16, bool DB>
 int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, KS, NS>;
-    constexpr size_t lds = (size_t)NS * kWStage + (NS == 6 ? 2 : 1) * G::PATCH;
+    constexpr size_t lds = (size_t)NS * kWStage + (DB ? 2 : 1) * G::PATCH;
     static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
     static bool set = false;
     if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS, F16>),
+        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS, F16, DB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         set = true;
     }
@@ -476,7 +488,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
         (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_patch_kernel<W8, KS, NS, F16><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(b);
+        conv3x3_patch_kernel<W8, KS, NS, F16, DB><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(b);
         (void)hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
@@ -486,14 +498,14 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    conv3x3_patch_kernel<W8, KS, NS, F16><<<dim3((a.M / 256) * (a.N / 64), a.splitk > 1 ? a.splitk : 1), 256 * KS, lds, st>>>(a);
+    conv3x3_patch_kernel<W8, KS, NS, F16, DB><<<dim3((a.M / 256) * (a.N / 64), a.splitk > 1 ? a.splitk : 1), 256 * KS, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
 
-template <bool W8, int KS, int NS>
+template <bool W8, int KS, int NS, bool DB = false>
 int launch(const ConvArgs& a, hipStream_t st) {
-    return a.f16 ? launch_t<W8, KS, NS, true>(a, st) : launch_t<W8, KS, NS, false>(a, st);
+    return a.f16 ? launch_t<W8, KS, NS, true, DB>(a, st) : launch_t<W8, KS, NS, false, DB>(a, st);
 }
 
 }  // namespace
@@ -511,8 +523,11 @@ int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream) {
     // variant 0: 4 waves, ring 3 (65-74 KB LDS: two workgroups per CU) -- many-workgroup layers
     // variant 1: 8 waves (wave pairs split each K-step), ring 5 -- few-workgroup deep layers, one workgroup per CU
     // variant 3: 8 waves, grouped ring of 2 x 3 slabs -- one barrier per kernel row (three K-steps)
-    if (a.Wo == 8) return variant == 0 ? launch<true, 1, 3>(a, stream) : variant == 3 ? launch<true, 2, 6>(a, stream) : launch<true, 2, 5>(a, stream);
-    return variant == 0 ? launch<false, 1, 3>(a, stream) : variant == 3 ? launch<false, 2, 6>(a, stream) : launch<false, 2, 5>(a, stream);
+    // variant 4: 3 with TWO patch buffers (the next chunk's patch lands under the current chunk's taps; 131 / 150 KB)
+    if (a.Wo == 8) return variant == 0 ? launch<true, 1, 3>(a, stream) : variant == 3 ? launch<true, 2, 6>(a, stream) :
+                          variant == 4 ? launch<true, 2, 6, true>(a, stream) : launch<true, 2, 5>(a, stream);
+    return variant == 0 ? launch<false, 1, 3>(a, stream) : variant == 3 ? launch<false, 2, 6>(a, stream) :
+           variant == 4 ? launch<false, 2, 6, true>(a, stream) : launch<false, 2, 5>(a, stream);
 }
 
 }  // namespace spsp

@@ -214,7 +214,7 @@ struct spsp_regressor {
     bool conv1_patch;      // stem through conv1_patch.hip
     bool use_wres;         // layer1 through conv_wres.hip
     int patch_splitk[4];   // split-K factor of the patch kernel per stage (deep stages have fewer tiles than CUs at 32 crops)
-    int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs), 3: 1 + grouped ring
+    int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs), 3: 1 + grouped ring, 4: 3 + two patch buffers
 };
 
 namespace {
@@ -250,8 +250,8 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     if (L >= 0 && r->use_patch && conv_patch_supported(a)) {
         const int v = r->patch_variant[L];
-        const int kid3 = a.Wo == 8 ? (v == 3 ? kKPatchW8Grp : v ? kKPatchW8Big : kKPatchW8Small)
-                                   : (v == 3 ? kKPatchW16Grp : v ? kKPatchW16Big : kKPatchW16Small);
+        const int kid3 = a.Wo == 8 ? (v >= 3 ? kKPatchW8Grp : v ? kKPatchW8Big : kKPatchW8Small)
+                                   : (v >= 3 ? kKPatchW16Grp : v ? kKPatchW16Big : kKPatchW16Small);
         int sk = r->patch_splitk[L];
         while (sk > 1 && (a.chunks % sk != 0 || (size_t)sk * a.M * a.N > r->slab_floats)) sk >>= 1;
         if (sk > 1) { a.splitk = sk; a.part = r->slab; }
@@ -356,7 +356,11 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         if (const char* pe = getenv("SPSP_CONV_WRES")) r->use_wres = atoi(pe) != 0;
         r->conv1_patch = true;
         if (const char* pe = getenv("SPSP_CONV1_PATCH")) r->conv1_patch = atoi(pe) != 0;
-        const int def_v[4] = {3, 3, 3, 3};   // measured at 32 crops: 8 waves + grouped ring (one barrier per kernel row) wins on every stage
+        // measured at 32 crops: 8 waves + grouped ring (one barrier per kernel row) on every stage; two patch buffers
+        // where the layer has fewer tiles than the chip has CUs (layer3, layer4).  Layer2 fills every CU exactly once
+        // and keeps ONE patch buffer (89 KB), so that a fit workgroup (38 KB) already resident on a CU does not push
+        // its tile into a second round.  A/B of 3 runs each: 3333 87.4 k, 4444 88.4 k, 3344 88.6 k, 3334 88.7 k players/s.
+        const int def_v[4] = {3, 3, 4, 4};
         for (int L = 0; L < 4; ++L) r->patch_variant[L] = def_v[L];
         for (int L = 0; L < 4; ++L) r->patch_splitk[L] = 1;
         if (const char* ps = getenv("SPSP_PATCH_SPLITK"))      // e.g. "1124"
