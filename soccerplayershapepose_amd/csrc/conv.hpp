@@ -28,6 +28,7 @@ struct ConvArgs {
     int relu;
     float* part;             // split-K: fp32 slabs [splitk][M][N] (conv_ring only)
     int splitk;              // 1 = no split
+    unsigned int* counter;   // conv_wres: device word, zero before the launch -- dynamic tile scheduler (atomicAdd)
     int f16;                 // element type of in / w / res / out: 0 = bf16, 1 = fp16 (conv_elem.hpp)
     unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of workgroup 0
 };

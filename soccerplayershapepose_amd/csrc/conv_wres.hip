@@ -40,7 +40,7 @@ constexpr int kWAll = 9 * kWSlab;                // 73 728 B
 constexpr int kNPix = 324, kNDma = 41;           // 18 x 18 patch, 8 pixels per 1-KiB DMA piece
 constexpr int kPatch = kNDma * 1024;             // 41 984 B
 constexpr int kStage = 256 * 128;                // epilogue staging tile [256 px][128 B]
-constexpr int kLds = kWAll + kPatch + kStage;    // 148 480 B
+constexpr int kLds = kWAll + kPatch + kStage + 16; // 148 496 B (last 16 B: tile-id broadcast slot)
 
 #ifdef SPSP_CONV_STAMPS
 #define WSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
@@ -54,12 +54,20 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     unsigned char* const wlds = smem;
     unsigned char* const patch = smem + kWAll;
     unsigned char* const stage = smem + kWAll + kPatch;
+    volatile int* const s_tile = reinterpret_cast<volatile int*>(smem + kWAll + kPatch + kStage);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = a.Wo, tpr = W / 16, tpi = tpr * tpr;
     const int ntiles = a.M / 256;
     const uint16_t* const in_ptr = a.in;
+
+    // first tile id (dynamic scheduler, see below) BEFORE any DMA is in flight: the atomic's return is then the only
+    // thing its s_waitcnt waits for
+    if (tid == 0) s_tile[0] = (int)atomicAdd(a.counter, 1u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s_tile[0] >= ntiles) return;                        // a late starter: the resident workgroups took every tile
 
     // ---- all nine weight slabs, once: piece p = 8 rows of one tap; lane l -> row l/8, physical chunk l%8 ----
     const int drow = lane >> 3, dchunk = lane & 7;
@@ -128,10 +136,15 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         }
     };
     WSTAMP(0);
-    int t = blockIdx.x;
+    // Dynamic tile scheduler: workgroups take tiles from a device counter (zero before the launch) instead of the
+    // static b, b + grid, ...  The grid is one workgroup per CU, but in the multi-stream pipeline some CUs are held by
+    // other kernels' workgroups (a fit workgroup keeps its CU's LDS for 230 us): with static tiles the workgroups of
+    // those CUs start late and the launch takes two rounds (measured 43 us under contention vs 21 us alone); with the
+    // counter the workgroups that ARE resident take the work and late starters find none.
+    int t = s_tile[0];                                      // fetched before the weight DMA was issued (top of the kernel)
     if (t < ntiles) issue_patch(t);
     bool first = true;
-    for (; t < ntiles; t += gridDim.x) {
+    while (t < ntiles) {
         // weights (first tile) + this tile's patch have landed.  On later tiles the patch DMA was issued BEFORE the
         // previous tile's 8 output stores per lane, and vmcnt counts stores too: leave those 8 in flight.
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -141,6 +154,13 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         if (first) { WSTAMP(1); } else { WSTAMP(5); }
         first = false;
+        // next tile id: issued now, read after the K loop.  Inline asm: hipcc's atomicAdd waits vmcnt(0) right behind the
+        // instruction (wave-aggregated lowering), which would park this wave on the previous tile's stores as well.
+        unsigned next_raw = 0;
+        if (tid == 0) {
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(next_raw) : "v"(a.counter), "v"(one) : "memory");
+        }
         if (has_res) issue_res(t);                            // lands during the K loop
 
         f32x4 acc[4][4];
@@ -193,8 +213,13 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
 #undef WRES_READ
 
         if (t == (int)blockIdx.x) { WSTAMP(2); } else { WSTAMP(6); }
-        __builtin_amdgcn_s_barrier();                         // every wave is done with the patch
-        const int tn = t + gridDim.x;
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_raw) : : "memory");     // the atomic's return (and the residual DMA, long landed)
+            s_tile[0] = (int)next_raw;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave is done with the patch; next tile id published
+        const int tn = s_tile[0];
         if (tn < ntiles) issue_patch(tn);                     // next tile's patch streams in under the epilogue
 
         // ---- epilogue through the LDS staging tile (see conv_patch.hip): whole 128-byte lines to and from HBM ----
@@ -235,6 +260,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         }
         if (t == (int)blockIdx.x) { WSTAMP(3); } else { WSTAMP(7); }
         // the staging tile is rewritten only after the next tile's first barrier
+        t = tn;
     }
 }
 
@@ -244,7 +270,7 @@ namespace spsp {
 
 bool conv_wres_supported(const ConvArgs& a) {
     return a.stride == 1 && a.kw_steps == 3 && a.chunks == 1 && a.nsteps == 9 && a.N == 64 && a.in_pix == 64 && a.in_off == 0 &&
-           a.M % 256 == 0 && a.Ho == a.Wo && a.Wo % 16 == 0 && a.splitk <= 1 && !a.pool_out && a.out;
+           a.M % 256 == 0 && a.Ho == a.Wo && a.Wo % 16 == 0 && a.splitk <= 1 && !a.pool_out && a.out && a.counter;
 }
 
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {

@@ -205,6 +205,8 @@ struct spsp_regressor {
     float *feats, *params, *h1, *h2;
     const uint16_t* stage_ptr[6];
     int last_B;
+    unsigned int* counters;  // tile-scheduler words of the persistent kernels (zeroed at the start of every forward)
+    int next_counter;
     float* slab;           // split-K fp32 slabs
     size_t slab_floats;
     // per residual stage: ring tile (kRingNone = first-generation kernel) and split-K factor
@@ -244,7 +246,9 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
     a.relu = relu;
     a.splitk = 1;
+    a.counter = r->counters + (r->next_counter < 15 ? r->next_counter : 15);
     if (L >= 0 && r->use_wres && conv_wres_supported(a)) {
+        ++r->next_counter;
         ProfScope ps(ctx, kKConvWres, st);
         return launch_conv_wres(a, ctx->num_cus, st);
     }
@@ -345,6 +349,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
             TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
     r->slab_floats = B * 65536 * 4;
     TRY(r->pool.alloc(&r->slab, r->slab_floats));
+    TRY(r->pool.alloc(&r->counters, 16, true));
     {   // conv plan for the residual stages; SPSP_CONV_PLAN="tile:splitk,tile:splitk,tile:splitk,tile:splitk"
         // with tile in {old, r128x128s3, r128x128s2, r128x64s3, r128x64s4, r64x128s3, r64x64s4} (tuning aid)
         const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};   // measured best at 32 crops
@@ -424,6 +429,9 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         TRY(spsp_proxy_pack(ctx, static_cast<const float*>(proxy), B, r->f16, r->x0, stream));
         x0 = r->x0;
     }
+    // tile-scheduler counters of this forward's persistent launches
+    SPSP_HIP_CHECK(hipMemsetAsync(r->counters, 0, 16 * sizeof(unsigned int), st));
+    r->next_counter = 0;
     // stem
     TRY(run_conv(ctx, r, 0, x0, kWH, kPad, r->c1, nullptr, 1, B, kTileConv1, nullptr, st));
     {
