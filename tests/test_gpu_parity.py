@@ -647,3 +647,23 @@ def test_handles_release_their_device_memory(regressor_sd_np, smpl_model_np, dev
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(dev)
     assert free0 - free1 < 8 << 20, f'{(free0 - free1) / 2**20:.1f} MiB not returned after 6 load/free cycles'
+
+
+def test_smpl_global_orientation_is_a_rigid_motion_about_the_root_joint(smpl_gpu, smpl_model_np, dev):
+    """Oracle-independent property of linear-blend skinning (smplx lbs): the global orientation enters only
+    the root transform, so replacing it by G R_0 moves every vertex and joint by the rigid map x -> G' (x - J_0) + J_0
+    with G' = G R_0 R_0^-1 = G applied about the root joint J_0 (which itself stays put).  Checked at full batch size
+    with random poses and shapes; tolerance 2e-6 m (fp32)."""
+    B = 32
+    R, betas, _ = S.pose_params(B, seed=91, body_deg=35, global_deg=40)
+    G2, _, _ = S.pose_params(B, seed=92, body_deg=0, global_deg=180)
+    Rt, bt = torch.from_numpy(R).to(dev), torch.from_numpy(betas).to(dev)
+    Gt = torch.from_numpy(G2[:, 0]).to(dev)                                   # [B,3,3] extra rotations
+    a = smpl_gpu(body_pose=Rt[:, 1:], global_orient=Rt[:, :1], betas=bt)
+    b = smpl_gpu(body_pose=Rt[:, 1:], global_orient=torch.matmul(Gt, Rt[:, 0]).unsqueeze(1), betas=bt)
+    J0 = a.joints[:, :1]                                                      # root joint = J_regressor . v_shaped, pose-independent
+    assert (b.joints[:, 0] - a.joints[:, 0]).abs().max().item() < 2e-6
+    want_v = torch.matmul(a.vertices - J0, Gt.transpose(1, 2)) + J0
+    want_j = torch.matmul(a.joints - J0, Gt.transpose(1, 2)) + J0
+    assert (b.vertices - want_v).abs().max().item() < 2e-6
+    assert (b.joints - want_j).abs().max().item() < 2e-6                      # all 90: chain, picked vertices, regressed
