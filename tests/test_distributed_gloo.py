@@ -35,7 +35,9 @@ def _worker(rank, world, port, n_total, q):
         full = torch.from_numpy(_records(n_total))
         lo, hi = shard_range(n_total, world, rank)
         out = all_gather_records(full[lo:hi].clone(), n_total)
-        q.put((rank, bool(torch.equal(out, full)), tuple(out.shape)))
+        out2, work = all_gather_records(full[lo:hi].clone(), n_total, async_op=True)
+        work.wait()
+        q.put((rank, bool(torch.equal(out, full)) and bool(torch.equal(out2, full)), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
