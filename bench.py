@@ -2,19 +2,24 @@
 """bench.py -- players/sec end-to-end (backbone -> rot6d -> 50-iter pose+shape fit -> SMPL forward -> vertices)
 on synthetic 256x256 proxy crops, one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (torch.distributed.run, as
+fresh children, BEFORE anything here touches the GPU) and relays rank 0's line; under an existing launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) it is one of the ranks.
 
 A "step" is one pass of the hot path over one batch of 32 crops per GPU (BASELINE.json configs[1]), inputs
 already resident in HBM in the backbone-native layout.  With N > 1 every rank processes its own 32 crops (weak
 scaling, crops shard data-parallel with no data-path collective) and the step ends with ONE RCCL all-gather of the
-packed per-player record [cam | R | betas] = 229 fp32.  Rank 0 prints ONE JSON line.
+packed per-player record [cam | R | betas] = 229 fp32, issued through the library's own
+spsp_allgather_records on the slot's stream.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,16 +34,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 BATCH_PER_GPU = 32
+FRAME_PLAYERS = 22                      # BASELINE.json configs[3]: one match frame
 FIT_ITERS = 50
 # algorithmic work per player (SURVEY 8d / BASELINE.md section 4)
 FLOP_CONV1 = 2 * 924_844_032            # conv1 7x7/2, 18 -> 64, real (unpadded) MACs
-FLOP_L1CONV = 2 * 150_994_944           # one 3x3 64->64 conv at 64x64
+FLOP_L1CONV = 2 * 150_994_944           # one 3x3 stride-1 conv of ResNet-18 (every one has the same MACs per crop)
 FLOP_BACKBONE = 2 * 3_139_436_544
-MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, MI355X_MICROARCH.md chip table
+MFMA_PEAK_TFLOPS = 2500.0               # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -47,44 +53,177 @@ def parse():
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth', type=int, default=4, help='pipeline slots (HIP streams); 1 = strictly serial steps')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16'], help='backbone storage / MFMA element type')
+    ap.add_argument('--precision', default='f16', choices=['bf16', 'f16'],
+                    help='backbone storage / MFMA element type.  f16 (default): the mode whose vertices stay within the '
+                         'north-star 1e-3 m of the all-fp32 CPU path; bf16: same bytes and MFMA rate, ~1.5e-3 m')
+    ap.add_argument('--no-alt-precision', action='store_true', help='skip the second (other element type) throughput figure')
     ap.add_argument('--from-detections', action='store_true',
                     help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
     ap.add_argument('--rehearse-dist', action='store_true',
-                    help='run the N>1 code path (RCCL process group, per-step all-gather, barriers) even with one rank')
+                    help='run the N>1 code path (RCCL communicators, per-step all-gather, barriers) even with one rank')
+    ap.add_argument('--exchange', default='abi', choices=['abi', 'torch'],
+                    help='N>1 exchange step: abi = spsp_allgather_records (the library\'s RCCL call on the slot stream), '
+                         'torch = torch.distributed.all_gather_into_tensor')
     ap.add_argument('--graphs', action='store_true', help='replay each slot\'s step from a captured HIP graph (no in-region kernel events)')
-    ap.add_argument('--cpu-sample', type=int, default=64, help='players timed through the CPU oracle (64: ~12 s on 16 threads)')
-    ap.add_argument('--cpu-threads', type=int, default=16, help="host threads for the CPU oracle (the GPU box's CPU share)")
-    return ap.parse_args()
+    ap.add_argument('--cpu-fit-sample', type=int, default=16, help='players fitted by the CPU oracle (0.15-0.2 s each)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='host threads for the CPU oracle; 0 = all physical cores this process may use')
+    ap.add_argument('--cpu-rehearsal', action='store_true',
+                    help='launcher / exchange rehearsal on gloo without a GPU (CPU test of the --gpus N path): no kernels run, value is null')
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(sd, model, x_nchw, tgt, n, threads):
-    """The oracle (restated reference path, PyTorch-CPU fp32, full SMPL.forward + autograd + Adam per fit
-    iteration) timed on this box's host cores over a bounded sample.  Checker timed as a BASELINE only."""
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks as FRESH children (torch.distributed.run) and relay rank 0's JSON
+    line.  This parent never initialises the GPU (device_count() only counts devices on this image), never execs."""
+    if not args.cpu_rehearsal:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode('utf-8', 'replace').splitlines() if ln.startswith('{') and '"metric"' in ln]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout.decode('utf-8', 'replace'))
+        raise SystemExit(p.returncode or 1)
+    sys.stdout.write(lines[-1] + '\n')
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
+def host_threads(requested):
+    """All physical cores this process may run on (the GPU box gives one GPU's CPU share), or the explicit request."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    if requested > 0:
+        return max(1, min(requested, allowed))
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or allowed
+    except Exception:
+        phys = allowed
+    return max(1, min(phys, allowed))
+
+
+def cpu_rehearsal(args, rank, world):
+    """The launcher + exchange path on gloo with no GPU: shards, padded all-gather, barriers, max-over-ranks time."""
+    from soccerplayershapepose_amd.sharding import all_gather_records, shard_range
+    dist.init_process_group('gloo')
+    B = args.batch
+    g = torch.Generator().manual_seed(7)
+    full = torch.rand((world * B, 229), generator=g)
+    lo, hi = shard_range(world * B, world, rank)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = all_gather_records(full[lo:hi].clone(), world * B)
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = bool(torch.equal(out, full))
+    # ragged frame (22 players -> 3,3,3,... per rank), padded to equal blocks
+    flo, fhi = shard_range(FRAME_PLAYERS, world, rank)
+    frame = all_gather_records(full[flo:fhi].clone(), FRAME_PLAYERS)
+    ok = ok and bool(torch.equal(frame, full[:FRAME_PLAYERS]))
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    line = {'metric': 'players/sec end-to-end (backbone+SMPL+fit) on 256x256 crops', 'value': None, 'unit': 'players/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el.item() / max(1, args.steps),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision,
+            'data': 'launcher rehearsal on gloo: no GPU work, exchange step only',
+            'config': {'workload': 'launcher + exchange rehearsal', 'crops_per_gpu': B, 'global_batch': world * B,
+                       'parallelism': f'dp{world}'}, 'exchange_ok': bool(flag.item())}
+    dist.destroy_process_group()
+    return line if rank == 0 else None
+
+
+def cpu_baseline(sd, model, x_nchw, tgt, n_fit, threads, gpu_pre, gpu_post):
+    """The oracle (restated reference path, PyTorch-CPU fp32: full SMPL.forward + autograd + torch.optim.Adam per fit
+    iteration) timed on this box's host cores, stage by stage: backbone+IEF at B=1 and B=32, the 50-iteration
+    fit per player, the SMPL forward; on all physical cores and on one.  It is the CHECKER timed as a reported baseline,
+    and the same outputs give the bench line its own parity figures against the GPU result (gpu_pre: vertices of
+    regressor -> SMPL, gpu_post: vertices after the fit, both [B,6890,3] for the players of the batch)."""
     from soccerplayershapepose_amd import synthetic as S
     from oracle import regressor as OR, geometry as G, fit as OF, smpl as OS
-    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
-    threads = torch.get_num_threads()
     osmpl = OS.OracleSMPL(model)
-    idx = [i % x_nchw.shape[0] for i in range(n)]           # the batch's players, cycled if the sample is larger
-    t0 = time.perf_counter()
-    parts = [OR.regressor_forward(sd, x_nchw[idx[i:i + 32]], S.mean_params()) for i in range(0, n, 32)]
-    cam, pose, shape = (torch.cat([p[k] for p in parts]) for k in range(3))
-    R = G.rot6d_to_rotmat(pose).view(n, 24, 3, 3)
-    t1 = time.perf_counter()
-    for i in range(n):
-        r = OF.fit_pose_shape(osmpl, R[i:i + 1, 1:], R[i:i + 1, :1], shape[i:i + 1], tgt[idx[i]], cam[i:i + 1], iters=FIT_ITERS)
+    mp = S.mean_params()
+    B = x_nchw.shape[0]
+
+    def timeit(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    stages = {}
+    torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
+    # backbone + IEF (a2-a4)
+    t_b32 = timeit(lambda: OR.regressor_forward(sd, x_nchw, mp), 1, 2)
+    t_b1 = timeit(lambda: OR.regressor_forward(sd, x_nchw[:1], mp), 3, 5)
+    cam, pose, shape = OR.regressor_forward(sd, x_nchw, mp)
+    R = G.rot6d_to_rotmat(pose).view(B, 24, 3, 3)
+    with torch.no_grad():
+        pre = osmpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=shape).vertices
+        t_s32 = timeit(lambda: osmpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=shape), 1, 3)
+        t_s1 = timeit(lambda: osmpl(body_pose=R[:1, 1:], global_orient=R[:1, :1], betas=shape[:1]), 3, 5)
+    # the fit (a9/a10), one player at a time as the reference drives it
+    n_fit = max(1, min(n_fit, B))
+    post, t_fit = [], []
+    for i in range(n_fit):
+        t0 = time.perf_counter()
+        r = OF.fit_pose_shape(osmpl, R[i:i + 1, 1:], R[i:i + 1, :1], shape[i:i + 1], tgt[i], cam[i:i + 1], iters=FIT_ITERS)
+        t_fit.append(time.perf_counter() - t0)
         body, Gm, be, ca, _ = r['last']
         with torch.no_grad():
-            osmpl(body_pose=body, global_orient=Gm, betas=be)
-    t2 = time.perf_counter()
-    return {'value': n / (t2 - t0), 'unit': 'players/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n} players end-to-end (regressor {t1 - t0:.2f}s + {FIT_ITERS}-iter fit & SMPL {t2 - t1:.2f}s), '
-                      f'torch-CPU fp32 oracle, {threads} threads'}
+            post.append(osmpl(body_pose=body, global_orient=Gm, betas=be).vertices[0])
+    t_fit_n = float(np.median(t_fit[1:] if len(t_fit) > 1 else t_fit))
+    # one thread
+    torch.set_num_threads(1)
+    t1_b1 = timeit(lambda: OR.regressor_forward(sd, x_nchw[:1], mp), 1, 2)
+    t0 = time.perf_counter()
+    OF.fit_pose_shape(osmpl, R[:1, 1:], R[:1, :1], shape[:1], tgt[0], cam[:1], iters=FIT_ITERS)
+    t1_fit = time.perf_counter() - t0
+    with torch.no_grad():
+        t1_s1 = timeit(lambda: osmpl(body_pose=R[:1, 1:], global_orient=R[:1, :1], betas=shape[:1]), 1, 3)
+    torch.set_num_threads(threads)
+    per_player = t_b32 / B + t_fit_n + t_s32 / B            # best CPU schedule: batched backbone + SMPL, per-player fit
+    stages = {'threads': threads, 'backbone_ief_B32_s': t_b32, 'backbone_ief_B1_s': t_b1, 'fit_50it_per_player_s': t_fit_n,
+              'smpl_forward_B32_s': t_s32, 'smpl_forward_B1_s': t_s1,
+              'one_thread': {'backbone_ief_B1_s': t1_b1, 'fit_50it_per_player_s': t1_fit, 'smpl_forward_B1_s': t1_s1,
+                             'players_per_s': 1.0 / (t1_b1 + t1_fit + t1_s1)}}
+    # parity of THIS run's GPU result against the all-fp32 CPU path, same players
+    pre_dev = (gpu_pre.cpu() - pre).abs().amax(dim=(1, 2))
+    post_dev = torch.stack([(gpu_post[i].cpu() - post[i]).abs().max() for i in range(n_fit)])
+    parity = {'reference': 'all-fp32 CPU oracle, same crops and fit targets', 'tolerance_m': 1e-3,
+              'pre_fit_players': int(B), 'pre_fit_max_m': float(pre_dev.max()),
+              'post_fit_players': int(n_fit), 'post_fit_median_m': float(post_dev.median()), 'post_fit_max_m': float(post_dev.max())}
+    base = {'value': 1.0 / per_player, 'unit': 'players/s', 'cores': threads, 'kind': 'port',
+            'sample': f'backbone+IEF on {B} crops (B=32 x2, B=1 x5), {n_fit} players through the {FIT_ITERS}-iteration fit, '
+                      f'SMPL forward B=32 x3 / B=1 x5; torch-CPU fp32 oracle on {threads} threads (all physical cores of this '
+                      f'process\'s CPU share) + a 1-thread figure', 'stages': stages}
+    return base, parity
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        launch_ranks(args, argv)
     # stdout carries exactly ONE line, the JSON result: native libraries write banners there (RCCL prints its version
     # block to stdout at communicator creation), so fd 1 is pointed at stderr for the duration of the run and the
     # result line goes to a saved copy of the original stdout.
@@ -94,8 +233,15 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.cpu_rehearsal:
+        line = cpu_rehearsal(args, rank, world)
+        if line is not None:
+            os.write(result_fd, (json.dumps(line) + '\n').encode())
+        return
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.rehearse_dist
@@ -110,30 +256,32 @@ def main():
     from soccerplayershapepose_amd import runtime as rt
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
     from soccerplayershapepose_amd.models.smpl_official import SMPL
-    from soccerplayershapepose_amd.player_recon import PlayerPipeline, pack_record
-    from soccerplayershapepose_amd.sharding import all_gather_records
+    from soccerplayershapepose_amd.player_recon import PlayerPipeline, reconstruct_players
+    from soccerplayershapepose_amd.sharding import RecordExchange, shard_range
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
 
     B = args.batch
     sd = S.regressor_state_dict(seed=0)
     model = S.smpl_model(seed=0)
-    def make_regressor():
-        m = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=args.precision)
-        return m.load_state_dict(sd)
 
-    def make_smpl():
-        return SMPL(model, max_batch=B)
+    def make_pipe(precision):
+        mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=precision).load_state_dict(sd)
+        mk_s = lambda: SMPL(model, max_batch=B)
+        return PlayerPipeline(mk_r, mk_s, dev, depth=max(1, args.depth))
 
-    pipe = PlayerPipeline(make_regressor, make_smpl, dev, depth=max(1, args.depth))
+    pipe = make_pipe(args.precision)
     reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl
     r = rt.get(dev)
+    exchange = RecordExchange(dev, mode=args.exchange) if use_dist else None
 
     # ---- synthetic inputs (seed 1234 + rank), resident in HBM in the backbone-native layout ----
     x_nchw, joints_in = S.proxy_crops(B, seed=1234 + rank)
-    native = reg.pack(torch.from_numpy(x_nchw).to(dev))
+    x_dev = torch.from_numpy(x_nchw).to(dev)
+    native = reg.pack(x_dev)
     # fit targets: the regressor-initialised model, perturbed + 1 px noise; set-up, untimed
     cam0, pose0, shape0 = reg(native)
     R0 = rot6d_to_rotmat(pose0).view(B, 24, 3, 3)
+    pre_fit_vertices = smpl(full_pose=R0, betas=shape0).vertices.clone()
     R2, b2, _ = S.pose_params(B, seed=77 + rank, body_deg=8, global_deg=10)
     Rp = torch.matmul(torch.from_numpy(R2).to(dev), R0)
     jp = smpl(body_pose=Rp[:, 1:], global_orient=Rp[:, :1], betas=shape0 + torch.from_numpy(b2).to(dev) / 3,
@@ -150,16 +298,19 @@ def main():
         assert torch.equal(create_proxy_representation_batch(sil_dev, joints_dev, precision=args.precision).view(torch.int16),
                            native.view(torch.int16))
 
-    def step():
-        # one batch through the WHOLE path on the next pipeline slot (its own stream): [proxy builder ->] regressor ->
-        # rot6d -> 50-iter fit -> SMPL forward [-> all-gather of the records]
-        inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=args.precision) if args.from_detections else native
-        res = pipe.submit(inp, tgt, fit=args.fit, iters=FIT_ITERS)
-        if use_dist:
-            with torch.cuda.stream(res.stream):
-                res.gathered = all_gather_records(pack_record(res.cam, res.rotmats, res.betas), world * B,
-                                                  force_collective=True)
-        return res
+    def make_step(pipe_, native_, precision):
+        def step():
+            # one batch through the WHOLE path on the next pipeline slot (its own stream): [proxy builder ->] regressor ->
+            # rot6d -> 50-iter fit -> SMPL forward [-> all-gather of the records]
+            inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=precision) if args.from_detections else native_
+            res = pipe_.submit(inp, tgt, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+            if use_dist:
+                with torch.cuda.stream(res.stream):
+                    res.gathered = exchange.all_gather(res.record, world * B)
+            return res
+        return step
+
+    step = make_step(pipe, native, args.precision)
 
     def barrier():
         if use_dist:
@@ -195,50 +346,92 @@ def main():
     r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
     kernels_iso = read_profile(iso_steps)
     pipe._next = 0
-    # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all have the
-    # same shape: the stem (1 launch/step) and the 3x3 stride-1 kernels (every 3x3/1 conv of ResNet-18 has
-    # 150 994 944 MACs per crop, whatever its layer)
-    cands = {'conv1_half_kernel': FLOP_CONV1 * B, 'conv1_patch_kernel': FLOP_CONV1 * B,
-             'conv_igemm_kernel<128, 64, 128, 8>': FLOP_CONV1 * B}
-    for k in kernels_iso:
-        if k.startswith('conv3x3_'):
-            cands[k] = FLOP_L1CONV * B
-    dom = max(cands, key=lambda k: kernels_iso.get(k, {'us_per_step': 0})['us_per_step'])
+    # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all do the same
+    # algorithmic work (the library names it: spsp_profile_kernel_flop_per_crop > 0)
+    cands = {}
+    for k, v in kernels_iso.items():
+        fl = r.lib.spsp_profile_kernel_flop_per_crop(v['id'])
+        if fl > 0:
+            cands[k] = fl * B
+    dom = max(cands, key=lambda k: kernels_iso[k]['us_per_step'])
 
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides.  Only the dominant kernel keeps
     # its event pair here: a pair is a barrier on its in-order stream, and bracketing all ~60 launches of a step costs
     # ~15 % throughput (measured), which would make `value` a profile-mode number.
-    if args.graphs:
-        # each slot's step is captured into a HIP graph (untimed) and replayed; events are not recorded inside graphs
-        pipe.use_graphs = True
-        for _ in range(len(pipe.slots)):
-            step()
+    def timed(step_fn, pipe_, select_id):
+        if args.graphs:
+            # each slot's step is captured into a HIP graph (untimed) and replayed; events are not recorded inside graphs
+            pipe_.use_graphs = True
+            for _ in range(len(pipe_.slots)):
+                step_fn()
+            torch.cuda.synchronize()
+        elif select_id is not None:
+            r.check(r.lib.spsp_profile_select(r.ctx, select_id), 'spsp_profile_select')
+            r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
+        barrier()
         torch.cuda.synchronize()
-    else:
-        r.check(r.lib.spsp_profile_select(r.ctx, kernels_iso[dom]['id']), 'spsp_profile_select')
-        r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
-    r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = elapsed.item()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_ = step_fn()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
+        r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return el.item(), out_
+
+    elapsed, out = timed(step, pipe, kernels_iso[dom]['id'])
     if use_dist:        # every rank holds every player's record, in shard order
         assert out.gathered.shape == (world * B, 229) and torch.equal(out.gathered[rank * B:(rank + 1) * B, :3], out.cam)
     assert torch.isfinite(out.vertices).all() and out.vertices.abs().max().item() > 0.1
     kernels = read_profile(args.steps)
+    post_fit_vertices = out.vertices.clone()
+
+    # ---- BASELINE.json configs[3]: latency of ONE 22-player frame, nothing else in flight (players shard over the ranks
+    # 3,3,3,...; the frame is done when every rank holds every record)
+    flo, fhi = shard_range(FRAME_PLAYERS, world, rank)
+    fn = fhi - flo
+    lat = []
+    for i in range(25):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if fn > 0:
+            fres = reconstruct_players(reg, smpl, native[:fn], tgt[:fn], fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+        if use_dist:
+            rec = fres.record if fn > 0 else torch.zeros((0, 229), dtype=torch.float32, device=dev)
+            exchange.all_gather(rec, FRAME_PLAYERS)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat_t = torch.tensor(sorted(lat[5:])[len(lat[5:]) // 2], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(lat_t, op=dist.ReduceOp.MAX)
+    frame_latency_ms = 1e3 * lat_t.item()
+
+    # ---- the other element type, same steps: a second throughput figure (not `value`)
+    alt = None
+    if not args.no_alt_precision and not args.graphs:
+        alt_prec = 'bf16' if args.precision == 'f16' else 'f16'
+        del fres
+        pipe2 = make_pipe(alt_prec)
+        reg2 = pipe2.slots[0].regressor
+        native2 = reg2.pack(x_dev)
+        c2, p2, s2 = reg2(native2)
+        pre2 = smpl(full_pose=rot6d_to_rotmat(p2).view(B, 24, 3, 3), betas=s2).vertices.clone()
+        step2 = make_step(pipe2, native2, alt_prec)
+        for _ in range(min(args.warmup, 8)):
+            step2()
+        torch.cuda.synchronize()
+        el2, out2 = timed(step2, pipe2, None)
+        alt = {'dtype': alt_prec, 'value': world * B * args.steps / el2, 'ms_per_step': 1e3 * el2 / args.steps,
+               'pre_fit_vertices': pre2, 'post_fit_vertices': out2.vertices.clone()}
 
     if rank == 0:
         achieved = cands[dom] / (kernels[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels else None
-        achieved_iso = cands[dom] / (kernels_iso[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels_iso else None
+        achieved_iso = cands[dom] / (kernels_iso[dom]['avg_us'] * 1e-6) / 1e12
         conv_us = sum(v['us_per_step'] for k, v in kernels_iso.items() if k.startswith('conv'))
         pmc_path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         traffic = None
@@ -249,36 +442,64 @@ def main():
             'value': world * B * args.steps / elapsed, 'unit': 'players/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': f'batch-{B} 256x256 synthetic proxy crops per GPU: ResNet-18+IEF regressor ({args.precision} MFMA, '
+            'config': {'workload': f'batch-{B} 256x256 synthetic proxy crops per GPU: ResNet-18+IEF regressor ({args.precision} storage and MFMA, '
                                    f'fp32 accumulate) -> rot6d -> {FIT_ITERS}-iter {args.fit} Adam fit -> SMPL forward '
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if use_dist else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs),
-                       'proxy_built_on_gpu': bool(args.from_detections)},
+                       'proxy_built_on_gpu': bool(args.from_detections),
+                       'exchange': (exchange.describe() if exchange else None)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
             # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's
             # event pair also spans the time its workgroups share CUs with other batches' kernels; that figure is
             # kept as *_timed_region.
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved_iso, 'peak': MFMA_BF16_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': (achieved_iso / MFMA_BF16_PEAK_TFLOPS) if achieved_iso else None,
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved_iso, 'peak': MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved_iso / MFMA_PEAK_TFLOPS,
                          'traffic': traffic,
-                         'avg_us': kernels_iso.get(dom, {}).get('avg_us'),
+                         'avg_us': kernels_iso[dom]['avg_us'],
                          'flop_per_launch': cands[dom],
                          'avg_us_timed_region': kernels.get(dom, {}).get('avg_us'),
                          'achieved_timed_region': achieved,
                          'all_convs_tflops': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12) if conv_us else None,
-                         'end_to_end_backbone_tflops': FLOP_BACKBONE * B * args.steps / elapsed / 1e12},
+                         'end_to_end_backbone_tflops': FLOP_BACKBONE * world * B * args.steps / elapsed / 1e12,
+                         'end_to_end_backbone_frac': FLOP_BACKBONE * B * args.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS},
+            'latency': {'workload': f'one {FRAME_PLAYERS}-player match frame (BASELINE configs[3]) through the whole path, nothing else in '
+                                    f'flight, {world} GPU(s)' + (', players sharded 3,3,... + all-gather' if world > 1 else ''),
+                        'ms': frame_latency_ms},
             'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},
         }
+        if alt is not None:
+            line['alt_precision'] = {'dtype': alt['dtype'], 'value': alt['value'], 'unit': 'players/s', 'ms_per_step': alt['ms_per_step']}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_sample, args.cpu_threads)
+            threads = host_threads(args.cpu_threads)
+            base, parity = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_fit_sample, threads,
+                                        pre_fit_vertices, post_fit_vertices)
+            line['cpu_baseline'] = base
+            line['parity'] = dict(parity, dtype=args.precision)
+            if alt is not None:
+                _, parity2 = cpu_baseline_parity_only(sd, model, torch.from_numpy(x_nchw), alt['pre_fit_vertices'])
+                line['alt_precision']['parity'] = parity2
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.barrier()
+        if exchange:
+            exchange.close()
         dist.destroy_process_group()
+
+
+def cpu_baseline_parity_only(sd, model, x_nchw, gpu_pre):
+    """Pre-fit vertex deviation of a second element type against the all-fp32 oracle (no timing)."""
+    from soccerplayershapepose_amd import synthetic as S
+    from oracle import regressor as OR, geometry as G, smpl as OS
+    osmpl = OS.OracleSMPL(model)
+    cam, pose, shape = OR.regressor_forward(sd, x_nchw, S.mean_params())
+    R = G.rot6d_to_rotmat(pose).view(x_nchw.shape[0], 24, 3, 3)
+    with torch.no_grad():
+        pre = osmpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=shape).vertices
+    return None, {'pre_fit_players': int(x_nchw.shape[0]), 'pre_fit_max_m': float((gpu_pre.cpu() - pre).abs().max())}
 
 
 if __name__ == '__main__':

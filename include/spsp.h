@@ -69,6 +69,10 @@ int         spsp_profile_enable(spsp_ctx* ctx, int on);
 int         spsp_profile_select(spsp_ctx* ctx, int kernel_id);
 int         spsp_profile_num_kernels(void);
 const char* spsp_profile_kernel_name(int id);
+/* Algorithmic FLOPs one launch of kernel `id` does per crop, when every launch of it does the same work (the MFMA
+ * convolutions; 0 for everything else), and whether the default batch-32 plan launches the kernel. */
+double      spsp_profile_kernel_flop_per_crop(int id);
+int         spsp_profile_kernel_in_default_plan(int id);
 int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);
 /* Instead of the sums: one (kernel id, stream, start, stop) record per bracketed launch site, times in ms relative to the
  * first record; clears the records.  For timeline studies of the multi-stream pipeline (tools/timeline.py). */

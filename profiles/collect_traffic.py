@@ -10,6 +10,7 @@ tallied at 64 B), so the read side is doubled; WRITE_SIZE is exact for 16-B-per-
 import collections
 import csv
 import json
+import os
 import re
 import sys
 
@@ -18,25 +19,56 @@ def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
     name = re.sub(r'\(.*$', '', name)
-    # the last template argument of the conv kernels is the element type (false = bf16, true = fp16); the library's
-    # profile names (spsp_profile_kernel_name) leave it out
-    name = re.sub(r'<(false|true)>$', '', name)
-    name = re.sub(r', (false|true)>$', '>', name)
-    return name
+    return name.strip()
 
 
-def per_kernel(path):
+def split_template(name):
+    m = re.match(r'^([^<]+)<(.*)>$', name)
+    if not m:
+        return name, []
+    return m.group(1), [a.strip() for a in m.group(2).split(',')]
+
+
+def library_names():
+    """The kernel names of the library's own table (spsp_profile_kernel_name): the ONE source bench.py keys on."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from soccerplayershapepose_amd import _abi
+    lib = _abi.load()
+    out = []
+    for i in range(lib.spsp_profile_num_kernels()):
+        for part in lib.spsp_profile_kernel_name(i).decode().split('+'):
+            out.append(part)
+    return out
+
+
+def to_library_name(rocprof_name, names):
+    """rocprofv3 prints every template argument; the library's names stop after the arguments that select the tiling
+    (element type / buffering flags follow).  A rocprof kernel belongs to the library name with the same base and the
+    longest matching argument prefix."""
+    base, args = split_template(short(rocprof_name))
+    best = None
+    for n in names:
+        nb, na = split_template(n)
+        if nb == base and args[:len(na)] == na and (best is None or len(na) > len(split_template(best)[1])):
+            best = n
+    return best
+
+
+def per_kernel(path, names):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
-        agg[short(row['Kernel_Name'])].append(float(row['Counter_Value']))
+        k = to_library_name(row['Kernel_Name'], names)
+        if k is not None:
+            agg[k].append(float(row['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
-fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+if __name__ != '__main__':
+    raise SystemExit
+NAMES = library_names()
+fetch, write = per_kernel(sys.argv[1], NAMES), per_kernel(sys.argv[2], NAMES)
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    if not any(t in k for t in ('conv', 'fit_kernel', 'smpl_', 'fc_kernel', 'maxpool', 'rot6d')):
-        continue
     rd, wr = 2 * 1024 * fetch.get(k, 0.0), 1024 * write.get(k, 0.0)
     out[k] = {'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr}
 json.dump(out, open('profiles/hbm_traffic.json', 'w'), indent=1)

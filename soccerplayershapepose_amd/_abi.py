@@ -108,6 +108,8 @@ _PROTOS = {
     'spsp_profile_select': (C.c_int, [_vp, C.c_int]),
     'spsp_profile_num_kernels': (C.c_int, []),
     'spsp_profile_kernel_name': (C.c_char_p, [C.c_int]),
+    'spsp_profile_kernel_flop_per_crop': (C.c_double, [C.c_int]),
+    'spsp_profile_kernel_in_default_plan': (C.c_int, [C.c_int]),
     'spsp_profile_timeline': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'spsp_profile_read': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

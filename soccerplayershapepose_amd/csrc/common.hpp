@@ -53,6 +53,20 @@ struct DevicePool {
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
+// Kernels that need more than 64 KB of dynamic LDS must be told so once PER DEVICE (the attribute belongs to the
+// device's copy of the function): one flag per (kernel, device) -- a process may hold contexts on several GPUs.
+template <auto Kernel>
+inline int ensure_dynamic_lds(int bytes) {
+    static bool done[64] = {};
+    int dev = 0;
+    SPSP_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && done[dev]) return SPSP_OK;
+    SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < 64) done[dev] = true;
+    return SPSP_OK;
+}
+#define SPSP_TRY(expr) do { const int rc_ = (expr); if (rc_ != SPSP_OK) return rc_; } while (0)
+
 // float -> bf16 bits, round-to-nearest-even (host side; finite inputs).
 inline uint16_t f32_to_bf16_host(float f) {
     uint32_t u;

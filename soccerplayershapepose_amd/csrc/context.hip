@@ -38,17 +38,27 @@ void spsp_destroy(spsp_ctx* ctx) {
     delete ctx;
 }
 
-static const char* const kKernelNames[spsp::kKNumKernels] = {
-    "conv1_patch_kernel", "conv_igemm_kernel<128, 64, 128, 8>", "maxpool_kernel", "conv1_half_kernel",
-    "conv3x3_patch_kernel<false, 1, 3>", "conv3x3_patch_kernel<false, 2, 5>",
-    "conv3x3_patch_kernel<true, 1, 3>", "conv3x3_patch_kernel<true, 2, 5>",
-    "conv3x3_patch_kernel<false, 2, 6>", "conv3x3_patch_kernel<true, 2, 6>",
-    "conv3x3_wres_kernel", "conv_ring_kernel", "conv_igemm_kernel", "fc_kernel", "init_params_kernel+split_params_kernel",
-    "proxy_pack_kernel", "proxy_build_kernel", "rot6d_kernel", "fit_kernel", "smpl_chain_kernel", "smpl_skin_kernel",
-    "smpl_extra_joints_kernel", "relate_project_kernel+relate_attend_kernel"};
+// One row per profiled kernel id (common.hpp, KernelId): the name bench.py / profiles/collect_traffic.py match against
+// rocprofv3's kernel names (template arguments after the ones listed are element type / buffering flags), the
+// algorithmic FLOPs ONE launch does per crop when every launch of the kernel does the same work (0 otherwise: not a
+// roofline candidate), and whether the default batch-32 plan launches it.
+struct KernelRow { const char* name; double flop_per_crop; int in_default_plan; };
+static const double kFlopConv1 = 2.0 * 924844032.0, kFlop3x3 = 2.0 * 150994944.0;
+static const KernelRow kKernels[spsp::kKNumKernels] = {
+    {"conv1_patch_kernel", kFlopConv1, 0}, {"conv_igemm_kernel<128, 64, 128, 8>", kFlopConv1, 0}, {"maxpool_kernel", 0, 1},
+    {"conv1_half_kernel", kFlopConv1, 1},
+    {"conv3x3_patch_kernel<false, 1, 3>", kFlop3x3, 0}, {"conv3x3_patch_kernel<false, 2, 5>", kFlop3x3, 0},
+    {"conv3x3_patch_kernel<true, 1, 3>", kFlop3x3, 0}, {"conv3x3_patch_kernel<true, 2, 5>", kFlop3x3, 0},
+    {"conv3x3_patch_kernel<false, 2, 6>", kFlop3x3, 1}, {"conv3x3_patch_kernel<true, 2, 6>", kFlop3x3, 1},
+    {"conv3x3_wres_kernel", kFlop3x3, 1}, {"conv_ring_kernel", 0, 1}, {"conv_igemm_kernel", 0, 0}, {"fc_kernel", 0, 1},
+    {"init_params_kernel+split_params_kernel", 0, 1},
+    {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0}, {"rot6d_kernel", 0, 1}, {"fit_kernel", 0, 1}, {"smpl_chain_kernel", 0, 1},
+    {"smpl_skin_kernel", 0, 1}, {"smpl_extra_joints_kernel", 0, 1}, {"relate_project_kernel+relate_attend_kernel", 0, 0}};
 
 int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
-const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernelNames[id] : nullptr; }
+const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].name : nullptr; }
+double spsp_profile_kernel_flop_per_crop(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].flop_per_crop : 0.0; }
+int spsp_profile_kernel_in_default_plan(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].in_default_plan : 0; }
 
 int spsp_profile_enable(spsp_ctx* ctx, int on) {
     SPSP_REQUIRE(ctx, "spsp_profile_enable: NULL ctx");

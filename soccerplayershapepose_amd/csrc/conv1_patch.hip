@@ -315,33 +315,18 @@ __global__ __launch_bounds__(256) void conv1_half_kernel(const ConvArgs a) {
 
 namespace spsp {
 
-bool conv1_uses_half_tiles() {
-    static const bool half = getenv("SPSP_CONV1_HALF") ? atoi(getenv("SPSP_CONV1_HALF")) != 0 : true;
-    return half;
-}
+bool conv1_uses_half_tiles() { return true; }
 
 int launch_conv1_patch(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(a.N == 64 && a.Ho == 128 && a.Wo == 128 && a.nsteps == 7 && a.stride == 2 && a.in_off == 0 &&
                      a.in_pix == 18 && a.in_row == 264 * 18,
                  "conv1_patch: geometry is fixed to the 7x7/2 stem on the [262,264,18] native layout");
-    static bool set = false;
-    if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_patch_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_patch_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-        set = true;
-    }
+    SPSP_TRY(ensure_dynamic_lds<&conv1_patch_kernel<false>>(kLds));
+    SPSP_TRY(ensure_dynamic_lds<&conv1_patch_kernel<true>>(kLds));
     const int B = a.M / (128 * 128);
     if (conv1_uses_half_tiles()) {
-        static bool hset = false;
-        if (!hset) {
-            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_half_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kHLds));
-            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_half_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, kHLds));
-            hset = true;
-        }
+        SPSP_TRY(ensure_dynamic_lds<&conv1_half_kernel<false>>(kHLds));
+        SPSP_TRY(ensure_dynamic_lds<&conv1_half_kernel<true>>(kHLds));
         if (a.f16) conv1_half_kernel<true><<<dim3(B * 64), 256, kHLds, st>>>(a);
         else conv1_half_kernel<false><<<dim3(B * 64), 256, kHLds, st>>>(a);
         SPSP_HIP_CHECK(hipGetLastError());

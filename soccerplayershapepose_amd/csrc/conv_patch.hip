@@ -478,12 +478,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, KS, NS>;
     constexpr size_t lds = (size_t)NS * kWStage + (DB ? 2 : 1) * G::PATCH;
     static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
-    static bool set = false;
-    if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<W8, KS, NS, F16, DB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        set = true;
-    }
+    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, KS, NS, F16, DB>>((int)lds)));
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;

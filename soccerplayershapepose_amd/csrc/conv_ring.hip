@@ -265,12 +265,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     const int tiles = (a.M / BM) * (a.N / BN);
     if (a.splitk > 1) {
         SPSP_REQUIRE(a.part != nullptr, "conv_ring: split-K needs a slab workspace");
-        static bool set = false;
-        if (!set) {
-            SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, NS, true, F16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            set = true;
-        }
+        SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, true, F16>>((int)lds)));
         conv_ring_kernel<BM, BN, NS, true, F16><<<dim3(tiles, a.splitk), 256, lds, st>>>(a);
         SPSP_HIP_CHECK(hipGetLastError());
         const size_t total = (size_t)a.M * (a.N / 4);
@@ -283,12 +278,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
     SPSP_REQUIRE(!a.pool_out || BM == a.Ho * a.Wo, "conv_ring: fused avg-pool needs one image per M tile");
-    static bool set = false;
-    if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<BM, BN, NS, false, F16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        set = true;
-    }
+    SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, false, F16>>((int)lds)));
     conv_ring_kernel<BM, BN, NS, false, F16><<<dim3(tiles, 1), 256, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;

@@ -275,14 +275,8 @@ bool conv_wres_supported(const ConvArgs& a) {
 
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
     SPSP_REQUIRE(conv_wres_supported(a), "conv_wres: needs a 3x3 stride-1 64->64 convolution on a map that is a multiple of 16 wide");
-    static bool set = false;
-    if (!set) {
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wres_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-        SPSP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wres_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-        set = true;
-    }
+    SPSP_TRY(ensure_dynamic_lds<&conv3x3_wres_kernel<false>>(kLds));
+    SPSP_TRY(ensure_dynamic_lds<&conv3x3_wres_kernel<true>>(kLds));
     const int ntiles = a.M / 256;
     const int grid = ntiles < num_cus ? ntiles : num_cus;       // persistent: one workgroup per CU (147 KB of LDS each)
 #ifdef SPSP_CONV_STAMPS

@@ -11,6 +11,16 @@
 namespace {
 using namespace spsp;
 
+// Between two phases that run back to back inside ONE wavefront (no workgroup barrier): the hardware issues a wave's
+// LDS instructions in order, so the earlier phase's ds_write is visible to the later phase's ds_read of any lane.  What
+// must not happen is the COMPILER moving one lane's read above another phase's write: a wavefront-scope release /
+// acquire pair around a wave barrier pins the order (zero instructions are emitted for it).
+__device__ __forceinline__ void wave_phase_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const float* __restrict__ fitc,
                                                  const int* __restrict__ parents, const int* __restrict__ level_joints,
                                                  const int* __restrict__ level_start, const int* __restrict__ child_start,
@@ -54,23 +64,24 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         if (wave0) {
 #pragma unroll
             for (int l = 1; l < kMaxLevels; ++l)       // static l: the per-lane role tables stay in registers
-                if (l < L) fit_chain_level(s, r, l);
+                if (l < L) { fit_chain_level(s, r, l); wave_phase_fence(); }
         }
         STAMP(2);
         __syncthreads();
         STAMP(3);
         fit_p4(s, r, lane);                       __syncthreads();
         STAMP(4);
-        if (wave0) { fit_p5(s, lane); fit_p6(s, r, lane, P); }
+        if (wave0) { fit_p5(s, lane); wave_phase_fence(); fit_p6(s, r, lane, P); }
         STAMP(5);
         __syncthreads();
         fit_p7(s, r, lane);                       __syncthreads();
         STAMP(6);
         if (wave0) {
             fit_p8(s, lane, P, it, lh, eh);
+            wave_phase_fence();
 #pragma unroll
             for (int l = kMaxLevels - 2; l >= 0; --l)
-                if (l <= L - 2) fit_reverse_level(s, r, l);
+                if (l <= L - 2) { fit_reverse_level(s, r, l); wave_phase_fence(); }
         }
         STAMP(7);
         __syncthreads();
@@ -120,6 +131,7 @@ int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, 
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && s && cfg, "spsp_fit: NULL handle");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     SPSP_REQUIRE(B >= 0, "spsp_fit: negative batch");
     if (B == 0) return SPSP_OK;
     SPSP_REQUIRE(R && betas && cam && joints2d, "spsp_fit: NULL argument");

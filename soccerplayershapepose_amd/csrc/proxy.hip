@@ -75,6 +75,7 @@ int spsp_proxy_build(spsp_ctx* ctx, const void* silhouettes, int sil_format, con
                      int precision, void* native_out, void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && B >= 0, "spsp_proxy_build: bad arguments");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     if (B == 0) return SPSP_OK;
     SPSP_REQUIRE(silhouettes && joints2d && native_out, "spsp_proxy_build: NULL argument");
     SPSP_REQUIRE(sil_format == SPSP_SIL_U8 || sil_format == SPSP_SIL_F32, "spsp_proxy_build: unknown sil_format %d", sil_format);

@@ -213,7 +213,6 @@ struct spsp_regressor {
     RingTile ring[4];
     int splitk[4];
     bool use_patch;        // 3x3 stride-1 convs through conv_patch.hip
-    bool conv1_patch;      // stem through conv1_patch.hip
     bool use_wres;         // layer1 through conv_wres.hip
     int patch_splitk[4];   // split-K factor of the patch kernel per stage (deep stages have fewer tiles than CUs at 32 crops)
     int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs), 3: 1 + grouped ring, 4: 3 + two patch buffers
@@ -277,13 +276,12 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
             return launch_conv_ring(a, rt, st);
         }
     }
-    if (ci == 0 && r->conv1_patch) {
-        ProfScope ps(ctx, conv1_uses_half_tiles() ? kKConv1Half : kKConv1Patch, st);
+    if (ci == 0) {
+        ProfScope ps(ctx, kKConv1Half, st);
         return launch_conv1_patch(a, st);
     }
-    const int kid = tile == kTileConv1 ? kKConv1Igemm : kKConvIgemm;
-    ProfScope ps(ctx, kid, st);
-    return launch_conv(a, tile, st);
+    set_error("regressor: no kernel for conv %s at batch %d", d.name, B);
+    return SPSP_EINVAL;
 }
 
 }  // namespace
@@ -350,17 +348,12 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     r->slab_floats = B * 65536 * 4;
     TRY(r->pool.alloc(&r->slab, r->slab_floats));
     TRY(r->pool.alloc(&r->counters, 16, true));
-    {   // conv plan for the residual stages; SPSP_CONV_PLAN="tile:splitk,tile:splitk,tile:splitk,tile:splitk"
-        // with tile in {old, r128x128s3, r128x128s2, r128x64s3, r128x64s4, r64x128s3, r64x64s4} (tuning aid)
+    {   // conv plan for the residual stages
         const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};   // measured best at 32 crops
         const int def_s[4] = {1, 1, 1, 1};
         for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->splitk[L] = def_s[L]; }
         r->use_patch = true;
-        if (const char* pe = getenv("SPSP_CONV_PATCH")) r->use_patch = atoi(pe) != 0;
         r->use_wres = true;
-        if (const char* pe = getenv("SPSP_CONV_WRES")) r->use_wres = atoi(pe) != 0;
-        r->conv1_patch = true;
-        if (const char* pe = getenv("SPSP_CONV1_PATCH")) r->conv1_patch = atoi(pe) != 0;
         // measured at 32 crops: 8 waves + grouped ring (one barrier per kernel row) on every stage; two patch buffers
         // where the layer has fewer tiles than the chip has CUs (layer3, layer4).  Layer2 fills every CU exactly once
         // and keeps ONE patch buffer (89 KB), so that a fit workgroup (38 KB) already resident on a CU does not push
@@ -368,26 +361,14 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         const int def_v[4] = {3, 3, 4, 4};
         for (int L = 0; L < 4; ++L) r->patch_variant[L] = def_v[L];
         for (int L = 0; L < 4; ++L) r->patch_splitk[L] = 1;
+#ifdef SPSP_TUNING   // tuning builds only (make TUNING=1): plan overrides from the environment; the product has ONE plan
+        if (const char* pe = getenv("SPSP_CONV_PATCH")) r->use_patch = atoi(pe) != 0;
+        if (const char* pe = getenv("SPSP_CONV_WRES")) r->use_wres = atoi(pe) != 0;
         if (const char* ps = getenv("SPSP_PATCH_SPLITK"))      // e.g. "1124"
             for (int L = 0; L < 4 && ps[L]; ++L) r->patch_splitk[L] = ps[L] - '0';
         if (const char* pv = getenv("SPSP_PATCH_VARIANT"))       // e.g. "0111"
             for (int L = 0; L < 4 && pv[L]; ++L) r->patch_variant[L] = pv[L] - '0';
-        if (const char* env = getenv("SPSP_CONV_PLAN")) {
-            std::string e(env);
-            size_t pos = 0;
-            for (int L = 0; L < 4 && pos < e.size(); ++L) {
-                size_t end = e.find(',', pos);
-                if (end == std::string::npos) end = e.size();
-                std::string tok = e.substr(pos, end - pos);
-                pos = end + 1;
-                int sk = 1;
-                const size_t colon = tok.find(':');
-                if (colon != std::string::npos) { sk = atoi(tok.c_str() + colon + 1); tok = tok.substr(0, colon); }
-                const char* names[7] = {"r128x128s3", "r128x128s2", "r128x64s3", "r128x64s4", "r64x128s3", "r64x64s4", "old"};
-                for (int t = 0; t < 7; ++t)
-                    if (tok == names[t]) { r->ring[L] = (RingTile)t; r->splitk[L] = sk < 1 ? 1 : sk; }
-            }
-        }
+#endif
     }
     TRY(r->pool.alloc(&r->feats, B * kFeat));
     TRY(r->pool.alloc(&r->params, B * kNPar));
@@ -415,6 +396,7 @@ int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, int precision
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, float* cam,
                            float* pose6d, float* betas, float* feats, void* stream) {
     SPSP_REQUIRE(ctx && r, "spsp_regressor_forward: NULL handle");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     if (B == 0) return SPSP_OK;
     SPSP_REQUIRE(proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
     SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_forward: B=%d exceeds max_batch=%d", B, r->max_batch);

@@ -160,6 +160,7 @@ int spsp_relate_forward(spsp_ctx* ctx, spsp_relate* h, const float* pose_rotmats
                         void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && h, "spsp_relate_forward: NULL handle");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     if (N == 0) return SPSP_OK;
     SPSP_REQUIRE(pose_rotmats && boxes && out, "spsp_relate_forward: NULL argument");
     SPSP_REQUIRE(N > 0 && N <= h->max_players, "spsp_relate_forward: N=%d exceeds max_players=%d", N, h->max_players);

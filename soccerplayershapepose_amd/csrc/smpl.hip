@@ -227,6 +227,7 @@ int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
                       float* joints, void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && s, "spsp_smpl_forward: NULL handle");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     if (B == 0) return SPSP_OK;          // empty batch: nothing to do (pointers of empty tensors may be NULL)
     SPSP_REQUIRE(R && betas, "spsp_smpl_forward: NULL argument");
     SPSP_REQUIRE(B >= 0 && B <= s->max_batch, "spsp_smpl_forward: B=%d exceeds max_batch=%d", B, s->max_batch);

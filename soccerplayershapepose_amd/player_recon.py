@@ -92,13 +92,15 @@ def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp,
 
 
 def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape', iters=50, lr=None,
-                        select_mode=_abi.FIT_SELECT_LAST, return_vertices2d=False, pose_relation=None, boxes=None):
+                        select_mode=_abi.FIT_SELECT_LAST, return_vertices2d=False, pose_relation=None, boxes=None,
+                        return_record=False):
     """The hot path end to end for one batch (`evaluate_model_2d` core, `PR/PyTorch3DTest.py:3738-3776`):
         proxy_rep [B,18,256,256] -> regressor -> rot6d -> fit ('camera' = optimize_camera per player,
         'pose_shape' = single_view_optimization per player, None = skip) -> SMPL forward.
     `pose_relation` (a `models.regressor_relate.PoseRelationModule`) + `boxes` insert the reference's optional
     cross-player refinement between rot6d and the fit.
-    Returns cam [B,3], rotmats [B,24,3,3], betas [B,10], vertices [B,6890,3], joints [B,90,3], translation."""
+    Returns cam [B,3], rotmats [B,24,3,3], betas [B,10], vertices [B,6890,3], joints [B,90,3], translation; with
+    `return_record` also record [B,229] = [cam | R | betas], the all-gather payload of the multi-GPU path."""
     x, fmt = regressor.prepare_input(proxy_rep)
     r = rt.get(x.device)
     B = x.shape[0]
@@ -110,6 +112,10 @@ def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape
     vertices, joints, translation = f32(B, 6890, 3), f32(B, 90, 3), f32(B, 3)
     out = _abi.PipelineOut(cam=rt.ptr(cam).value, pose6d=rt.ptr(pose6d).value, betas=rt.ptr(betas).value, rotmats=rt.ptr(R).value,
                            vertices=rt.ptr(vertices).value, joints=rt.ptr(joints).value, translation=rt.ptr(translation).value)
+    record = None
+    if return_record:
+        record = f32(B, _abi.RECORD_FLOATS)
+        out.record = rt.ptr(record).value
     rel_handle = bx = None
     if pose_relation is not None:       # `use_relate`, PR/PyTorch3DTest.py:3758-3759: the batch is ONE frame's players
         if boxes is None:
@@ -131,7 +137,7 @@ def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape
                                 C.byref(cfg) if cfg is not None else None, B, config.FOCAL_LENGTH,
                                 config.proxy_rep_input_wh, C.byref(out), r.stream()), 'spsp_pipeline')
     res = SimpleNamespace(cam=cam, rotmats=R, betas=betas, vertices=vertices, joints=joints, translation=translation,
-                          pose6d=pose6d)
+                          pose6d=pose6d, record=record)
     if return_vertices2d:   # PR/PyTorch3DTest.py:3774-3776
         res.vertices2d = orthographic_project_to_pixels(vertices, cam, config.proxy_rep_input_wh)
     return res
@@ -182,13 +188,23 @@ class PlayerPipeline:
         the same slot is submitted to again (depth submits later)."""
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
-        slot.stream.wait_stream(torch.cuda.current_stream(self.device))     # inputs produced on the caller's stream
+        caller = torch.cuda.current_stream(self.device)
+        slot.stream.wait_stream(caller)                                     # inputs produced on the caller's stream
+        # The inputs were allocated on the caller's stream and are read on the slot's: tell the caching allocator, or a
+        # buffer the caller drops right after submit() is handed to the caller's next allocation while this batch still
+        # reads it.  Same for the results, allocated on the slot's stream and consumed on the caller's after `done`.
+        for t in (proxy_rep, joints2D, kw.get('boxes')):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(slot.stream)
         if self.use_graphs:
             return self._submit_graph(slot, proxy_rep, joints2D, kw)
         with torch.cuda.stream(slot.stream):
             res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
             res.done = torch.cuda.Event()
             res.done.record(slot.stream)
+        for t in vars(res).values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(caller)
         res.stream = slot.stream
         return res
 

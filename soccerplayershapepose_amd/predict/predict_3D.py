@@ -24,7 +24,7 @@ def create_proxy_representation(silhouette, joints2D, in_wh, out_wh):
     return np.transpose(proxy, [2, 0, 1])
 
 
-def create_proxy_representation_batch(silhouettes, joints2D, precision='bf16'):
+def create_proxy_representation_batch(silhouettes, joints2D, precision='f16'):
     """The same routine for a batch ON THE GPU, emitting the backbone's native input directly:
     silhouettes [B,512,512] (uint8 / bool / float32, values 0/1) and joints2D [B,17,2|3] (x, y[, conf]; 512-px
     space) -> [B,262,264,18] bf16 / fp16 device tensor, bit-identical to

@@ -62,3 +62,91 @@ def all_gather_records(local, n_total, group=None, force_collective=False, async
     if async_op:
         return torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0), _Done()
     return torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
+
+
+class RecordExchange:
+    """The exchange step of a multi-GPU run: ONE all-gather of the packed records per batch, on the CURRENT stream.
+
+    mode 'abi' (default): the library's own `spsp_allgather_records` (csrc/comm.hip: one ncclAllGather through the RCCL
+    copy this process already holds) on a communicator created here -- rank 0 draws the 128-byte unique id and
+    torch.distributed broadcasts it.  All ranks agree on the outcome of the communicator set-up: if it failed on any
+    rank, every rank falls back to `torch.distributed.all_gather_into_tensor` and `describe()` says so.
+    mode 'torch': torch.distributed only (also what the gloo CPU tests use)."""
+
+    def __init__(self, device, mode='abi', group=None):
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.mode = mode
+        self.note = ''
+        self._comm = None
+        self._rt = None
+        if mode == 'abi':
+            self._init_abi()
+
+    def _init_abi(self):
+        import ctypes as C
+        from . import runtime as rt
+        r = rt.get(self.device)
+        ident = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        err = ''
+        if self.rank == 0:
+            buf = (C.c_ubyte * 128)()
+            rc = r.lib.spsp_comm_unique_id(buf)
+            if rc != 0:
+                err = r.lib.spsp_last_error().decode('utf-8', 'replace')
+            else:
+                ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        if dist.is_initialized():
+            dist.broadcast(ident, src=0, group=self.group)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.device)
+        if not err:
+            host = bytes(ident.cpu().numpy().tobytes())
+            h = C.c_void_p()
+            with torch.cuda.device(self.device):
+                rc = r.lib.spsp_comm_init_rank(r.ctx, host, self.world, self.rank, C.byref(h))
+            if rc != 0:
+                err = r.lib.spsp_last_error().decode('utf-8', 'replace')
+                ok.zero_()
+            else:
+                self._comm = h
+        if dist.is_initialized():
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:          # collective decision: nobody uses a half-built communicator
+            self.close()
+            self.mode = 'torch'
+            self.note = f' (spsp_comm set-up failed on a rank{": " + err if err else ""}; fell back)'
+        self._rt = r
+
+    def describe(self):
+        how = 'spsp_allgather_records (libspsp RCCL call on the slot stream)' if self.mode == 'abi' else 'torch.distributed.all_gather_into_tensor'
+        return how + self.note
+
+    def all_gather(self, local, n_total):
+        """local [n_local, 229] (this rank's shard, shard_range order) -> [n_total, 229] on every rank."""
+        if self.mode != 'abi':
+            return all_gather_records(local, n_total, group=self.group, force_collective=True)
+        from . import runtime as rt
+        sizes = shard_sizes(n_total, self.world)
+        if local.shape[0] != sizes[self.rank]:
+            raise ValueError(f'rank {self.rank}: got {local.shape[0]} records, shard_sizes says {sizes[self.rank]}')
+        m = max(sizes)
+        padded = local.contiguous()
+        if local.shape[0] < m:
+            padded = torch.zeros((m, local.shape[1]), dtype=local.dtype, device=local.device)
+            padded[:local.shape[0]] = local
+        out = torch.empty((self.world * m, local.shape[1]), dtype=local.dtype, device=local.device)
+        r = self._rt
+        r.check(r.lib.spsp_allgather_records(r.ctx, self._comm, rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
+        padded.record_stream(torch.cuda.current_stream(self.device))
+        if all(s == m for s in sizes):
+            return out
+        return torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
+
+    def close(self):
+        if self._comm is not None:
+            self._rt = self._rt or None
+            from . import runtime as rt
+            rt.get(self.device).lib.spsp_comm_destroy(self._comm)
+            self._comm = None

@@ -51,9 +51,27 @@ def test_profile_kernel_names_and_native_layout_size():
     lib = _abi.load()
     n = lib.spsp_profile_num_kernels()
     names = [lib.spsp_profile_kernel_name(i).decode() for i in range(n)]
-    assert 'fit_kernel' in names and 'conv1_patch_kernel' in names and 'conv1_half_kernel' in names and 'conv3x3_wres_kernel' in names
-    assert sum(k.startswith('conv3x3_patch_kernel') for k in names) == 6 and len(set(names)) == n
+    assert 'fit_kernel' in names and len(set(names)) == n
     assert lib.spsp_proxy_native_bytes() == 262 * 264 * 18 * 2
+    # roofline candidates (every launch does the same algorithmic work) are MFMA convolutions of the default plan or fallbacks
+    cands = [names[i] for i in range(n) if lib.spsp_profile_kernel_flop_per_crop(i) > 0]
+    assert cands and all(k.startswith('conv') for k in cands)
+    assert lib.spsp_profile_kernel_flop_per_crop(-1) == 0 and lib.spsp_profile_kernel_in_default_plan(n) == 0
+
+
+def test_every_default_plan_kernel_resolves_in_the_committed_traffic_table():
+    """bench.py's roofline.traffic is profiles/hbm_traffic.json[<dominant kernel name>]: both sides take the kernel names
+    from the library's own table (profiles/collect_traffic.py maps rocprofv3's names onto it), so every kernel the
+    default batch-32 plan launches -- every possible dominant kernel in particular -- must be a key of the file."""
+    import json
+    lib = _abi.load()
+    table = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+    for i in range(lib.spsp_profile_num_kernels()):
+        if not lib.spsp_profile_kernel_in_default_plan(i):
+            continue
+        for name in lib.spsp_profile_kernel_name(i).decode().split('+'):
+            assert name in table, f'{name} (default plan) has no entry in profiles/hbm_traffic.json'
+            assert table[name]['hbm_bytes_per_launch'] > 0
 
 
 def test_smpl_array_validation_on_host(smpl_model_np):

@@ -72,3 +72,27 @@ def test_all_gather_even_shards_world2():
 def test_all_gather_ragged_shards_world2():
     for rank, ok, shape in _run(23):
         assert ok and shape == (23, 229)
+
+
+def test_bench_launcher_starts_the_ranks_itself_world2():
+    """`python bench.py --gpus 2` with no launcher around it must itself start 2 ranks (fresh children, before any GPU
+    call) and relay ONE JSON line saying n_gpus 2 / dp2.  --cpu-rehearsal swaps the GPU work for the exchange step on
+    gloo, so the launcher, the rendezvous, the padded all-gather and the max-over-ranks timing run here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--cpu-rehearsal'], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 64
+    assert d['exchange_ok'] is True and d['steps'] == 3
+    # a rank count the launcher did not create is refused
+    env2 = dict(env, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--cpu-rehearsal'], capture_output=True,
+                         text=True, timeout=120, env=env2)
+    assert bad.returncode != 0 and 'WORLD_SIZE=3' in bad.stderr
