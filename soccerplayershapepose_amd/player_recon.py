@@ -164,6 +164,24 @@ def unpack_record(rec):
     return cam, R, betas
 
 
+def _with_wait(res):
+    """Gives a pipeline result its `wait()`: the way to consume the tensors on ANOTHER stream than the slot's.  The
+    caller's current stream waits for the batch (`done`), and the result tensors -- allocated on the slot's stream --
+    are marked as used by the caller's stream, so that the caching allocator does not hand their memory to the slot's
+    next batch while a consumer kernel of the caller is still reading it.  (Done here and not in submit(): recording
+    the stream makes every free of a result go through an event, which costs throughput when results are only
+    synchronised on, as in bench.py.)"""
+    def wait(stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(res.stream.device)
+        st.wait_event(res.done)
+        for t in vars(res).values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(st)
+        return res
+    res.wait = wait
+    return res
+
+
 class PlayerPipeline:
     """Throughput mode of `reconstruct_players`: `depth` independent slots, each with its own HIP stream and its
     own regressor / SMPL handles (a handle's workspace serves one call in flight).  Batches are issued round-robin,
@@ -192,7 +210,7 @@ class PlayerPipeline:
         slot.stream.wait_stream(caller)                                     # inputs produced on the caller's stream
         # The inputs were allocated on the caller's stream and are read on the slot's: tell the caching allocator, or a
         # buffer the caller drops right after submit() is handed to the caller's next allocation while this batch still
-        # reads it.  Same for the results, allocated on the slot's stream and consumed on the caller's after `done`.
+        # reads it.  The results are allocated on the slot's stream: consume them on another stream through res.wait().
         for t in (proxy_rep, joints2D, kw.get('boxes')):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(slot.stream)
@@ -202,11 +220,8 @@ class PlayerPipeline:
             res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
             res.done = torch.cuda.Event()
             res.done.record(slot.stream)
-        for t in vars(res).values():
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(caller)
         res.stream = slot.stream
-        return res
+        return _with_wait(res)
 
     def _submit_graph(self, slot, proxy_rep, joints2D, kw):
         if not (torch.is_tensor(proxy_rep) and proxy_rep.is_cuda and torch.is_tensor(joints2D) and joints2D.is_cuda):
@@ -233,7 +248,7 @@ class PlayerPipeline:
             out.done = torch.cuda.Event()
             out.done.record(slot.stream)
         out.stream = slot.stream
-        return out
+        return _with_wait(out)
 
     def synchronize(self):
         for s in self.slots:

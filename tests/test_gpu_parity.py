@@ -455,6 +455,41 @@ def test_player_pipeline_streams_and_graph_replay_are_bit_identical_to_the_seria
         PlayerPipeline(mk_r, mk_s, dev, depth=1, use_graphs=True).submit(native, tgt.cpu().numpy())
 
 
+def test_player_pipeline_keeps_freshly_allocated_inputs_alive_across_streams(regressor_sd_np, smpl_model_np, dev):
+    """Every step hands the pipeline a FRESHLY allocated input with different content and drops it right after
+    submit(); the caller's stream then allocates and scribbles over same-sized buffers at once.  Without
+    record_stream() on the inputs the caching allocator gives the just-dropped block to that scribble while the slot's
+    stream still reads it (conv1 of the previous batch): every result must equal the serial path bit for bit.  Results
+    are consumed on the caller's stream through res.wait()."""
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    from soccerplayershapepose_amd.models.smpl_official import SMPL
+    from soccerplayershapepose_amd.player_recon import PlayerPipeline, reconstruct_players
+    B = 8
+    mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B).load_state_dict(regressor_sd_np)
+    mk_s = lambda: SMPL(smpl_model_np, max_batch=B)
+    x, _ = S.proxy_crops(3 * B, seed=21)
+    ref_reg, ref_smpl = mk_r().to(dev), mk_s().to(dev)
+    natives = [ref_reg.pack(torch.from_numpy(x[i * B:(i + 1) * B]).to(dev)) for i in range(3)]
+    tgts = [(torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(30 + i)) * 300 + 100).to(dev) for i in range(3)]
+    refs = [reconstruct_players(ref_reg, ref_smpl, natives[i], tgts[i], fit='pose_shape', iters=10).vertices.clone() for i in range(3)]
+    torch.cuda.synchronize()
+    pipe = PlayerPipeline(mk_r, mk_s, dev, depth=4)
+    sums, worst = [], 0.0
+    for step in range(12):
+        i = step % 3
+        inp, tg = natives[i].clone(), tgts[i].clone()            # fresh allocations on the caller's stream
+        res = pipe.submit(inp, tg, fit='pose_shape', iters=10)
+        del inp, tg
+        junk = [torch.full((B, 262, 264, 18), 7.0, dtype=natives[0].dtype, device=dev) for _ in range(2)]   # would reuse the dropped blocks
+        junk2 = torch.full((B, 17, 2), -1e6, device=dev)
+        res.wait()
+        sums.append((res.vertices - refs[i]).abs().max())         # consumed on the caller's stream
+        del res, junk, junk2
+    torch.cuda.synchronize()
+    worst = max(float(v) for v in sums)
+    assert worst == 0.0, f'pipelined results differ from the serial path by {worst} (input buffer reused while in flight?)'
+
+
 def test_smpl_forward_is_bit_stable_next_to_convolutions_on_other_streams(regressor_sd_np, smpl_model_np, dev):
     """Regression test for a cross-stream corruption found with tools/race_hunt2.py: with packed-fp32 VALU ops
     (`v_pk_fma_f32 ... op_sel`) in the skin kernel, ~35 % of SMPL forwards came out with wrong y-coordinates in
