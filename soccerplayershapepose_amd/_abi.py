@@ -152,11 +152,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('SPSP_LIB_PATH', LIB_PATH)      # diagnostic twins (csrc/libspsp_stamps.so) for tools/ only
+    if not os.path.exists(path):
         raise RuntimeError(
-            f'{LIB_PATH} not found: the HIP library is not built. Run `python -c "import __graft_entry__ as g; '
+            f'{path} not found: the HIP library is not built. Run `python -c "import __graft_entry__ as g; '
             f'g.build()"` (or `make -C soccerplayershapepose_amd/csrc`). There is no CPU fallback.')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

@@ -94,18 +94,13 @@ inline float bf16_to_f32_host(uint16_t h) {
 // ---- optional per-kernel timing (HIP events on the launch stream), for bench.py's roofline leg ------------
 namespace spsp {
 enum KernelId {
-    kKConv1Patch = 0, kKConv1Igemm, kKMaxpool,
-    kKConv1Half,       // conv1_half_kernel (stem, half-width tiles, two workgroups per CU)
-    kKPatchW16Small,   // conv3x3_patch_kernel<false, 1, 3>  (4-wave workgroups)
-    kKPatchW16Big,     // conv3x3_patch_kernel<false, 2, 5>  (8-wave workgroups)
-    kKPatchW8Small,    // conv3x3_patch_kernel<true, 1, 3>
-    kKPatchW8Big,      // conv3x3_patch_kernel<true, 2, 5>
-    kKPatchW16Grp,     // conv3x3_patch_kernel<false, 2, 6>  (8 waves, one barrier per kernel row)
-    kKPatchW8Grp,      // conv3x3_patch_kernel<true, 2, 6>
-    kKConvWres,        // conv3x3_wres_kernel (layer1)
-    kKConvRing,        // conv_ring_kernel<...> (stride-2 / 1x1 convs, fallbacks)
-    kKConvIgemm,       // conv_igemm_kernel<...> (first generation, fallbacks)
-    kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate, kKNumKernels
+    kKStem = 0,        // conv1_pool_kernel (conv1 + BN + ReLU + max-pool; weights in registers, rolling input window)
+    kKConvWres,        // conv3x3_wres_kernel (layer1: 3x3 / 1, 64 -> 64, weights resident in LDS, persistent)
+    kKPatchW16,        // conv3x3_patch_kernel<false, ...> (3x3 / 1 of layer2, layer3: 16 x 16-pixel tiles)
+    kKPatchW8,         // conv3x3_patch_kernel<true, ...>  (3x3 / 1 of layer4: four 8 x 8 images per tile)
+    kKConvRing,        // conv_ring_kernel<...> (stride-2 3x3 and 1x1 convs; every conv of a ragged batch)
+    kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate,
+    kKNumKernels
 };
 struct ProfRec { int id; hipEvent_t start, stop; hipStream_t stream; };
 }  // namespace spsp

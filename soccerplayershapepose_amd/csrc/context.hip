@@ -45,15 +45,11 @@ void spsp_destroy(spsp_ctx* ctx) {
 struct KernelRow { const char* name; double flop_per_crop; int in_default_plan; };
 static const double kFlopConv1 = 2.0 * 924844032.0, kFlop3x3 = 2.0 * 150994944.0;
 static const KernelRow kKernels[spsp::kKNumKernels] = {
-    {"conv1_patch_kernel", kFlopConv1, 0}, {"conv_igemm_kernel<128, 64, 128, 8>", kFlopConv1, 0}, {"maxpool_kernel", 0, 1},
-    {"conv1_half_kernel", kFlopConv1, 1},
-    {"conv3x3_patch_kernel<false, 1, 3>", kFlop3x3, 0}, {"conv3x3_patch_kernel<false, 2, 5>", kFlop3x3, 0},
-    {"conv3x3_patch_kernel<true, 1, 3>", kFlop3x3, 0}, {"conv3x3_patch_kernel<true, 2, 5>", kFlop3x3, 0},
-    {"conv3x3_patch_kernel<false, 2, 6>", kFlop3x3, 1}, {"conv3x3_patch_kernel<true, 2, 6>", kFlop3x3, 1},
-    {"conv3x3_wres_kernel", kFlop3x3, 1}, {"conv_ring_kernel", 0, 1}, {"conv_igemm_kernel", 0, 0}, {"fc_kernel", 0, 1},
-    {"init_params_kernel+split_params_kernel", 0, 1},
-    {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0}, {"rot6d_kernel", 0, 1}, {"fit_kernel", 0, 1}, {"smpl_chain_kernel", 0, 1},
-    {"smpl_skin_kernel", 0, 1}, {"smpl_extra_joints_kernel", 0, 1}, {"relate_project_kernel+relate_attend_kernel", 0, 0}};
+    {"conv1_pool_kernel", kFlopConv1, 1}, {"conv3x3_wres_kernel", kFlop3x3, 1},
+    {"conv3x3_patch_kernel<false>", kFlop3x3, 1}, {"conv3x3_patch_kernel<true>", kFlop3x3, 1}, {"conv_ring_kernel", 0, 1},
+    {"fc_kernel", 0, 1}, {"init_params_kernel+split_params_kernel", 0, 1}, {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0},
+    {"rot6d_kernel", 0, 1}, {"fit_kernel", 0, 1}, {"smpl_chain_kernel", 0, 1}, {"smpl_skin_kernel", 0, 1},
+    {"smpl_extra_joints_kernel", 0, 1}, {"relate_project_kernel+relate_attend_kernel", 0, 0}};
 
 int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
 const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].name : nullptr; }

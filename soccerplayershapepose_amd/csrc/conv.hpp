@@ -30,12 +30,16 @@ struct ConvArgs {
     int splitk;              // 1 = no split
     unsigned int* counter;   // conv_wres: device word, zero before the launch -- dynamic tile scheduler (atomicAdd)
     int f16;                 // element type of in / w / res / out: 0 = bf16, 1 = fp16 (conv_elem.hpp)
+    int xcd_n;               // conv_patch: XCDs along the channel blocks (tile order; set by launch_conv_patch)
+    // conv_ring: an optional SECOND convolution in the same launch -- the 1x1 stride-2 downsample of a residual stage rides
+    // with the stage's 3x3 stride-2 conv: same input pixels (the 3x3's centre tap), same output geometry, N2 more channel
+    // blocks whose K loop covers only the centre-tap steps.  w2 = [n2][chunks*64], no residual, no ReLU.
+    const uint16_t* w2;
+    const float* bias2;
+    uint16_t* out2;
+    int n2;
     unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of workgroup 0
 };
-
-enum ConvTile { kTile128x64 = 0, kTile128x128, kTile64x128, kTile64x64, kTileConv1 };
-
-int launch_conv(const ConvArgs& a, ConvTile tile, hipStream_t stream);
 
 // second generation (conv_ring.hip): LDS-DMA ring, BK = 64, optional split-K
 enum RingTile { kRing128x128s3 = 0, kRing128x128s2, kRing128x64s3, kRing128x64s4, kRing64x128s3, kRing64x64s4, kRingNone };
@@ -43,16 +47,14 @@ int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 
 // third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 px x 64 ch per workgroup
 bool conv_patch_supported(const ConvArgs& a);
-int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream);
-// second pass of a split-K convolution (a.splitk slabs in a.part): sum + bias (+ residual) + ReLU -> out (+ avg-pool)
-int launch_splitk_epilogue(const ConvArgs& a, hipStream_t stream);
+int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, hipStream_t stream);
 
 // conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
 bool conv_wres_supported(const ConvArgs& a);
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);
 
-// conv1_patch.hip: the 7x7/2 stem with an LDS-resident 13-row input patch (4 output rows x 128 px x 64 ch per workgroup)
-int launch_conv1_patch(const ConvArgs& a, hipStream_t stream);
-bool conv1_uses_half_tiles();   // true: conv1_half_kernel (default), false: conv1_patch_kernel (SPSP_CONV1_HALF=0)
+// conv_stem.hip: conv1 + BN + ReLU + max-pool in one kernel: native input [B][262][264][18] -> pooled map [B][66][66][64]
+int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
+                     hipStream_t stream);
 
 }  // namespace spsp

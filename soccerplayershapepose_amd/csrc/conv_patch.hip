@@ -23,19 +23,18 @@
 //   W >= 16 : tile = 16 x 16 pixels of one image, patch 18 x 18; wave w owns rows 4w..4w+3, MFMA tile j = one row.
 //   W == 8  : tile = 4 whole 8 x 8 images, patch 4 x (10 x 10); wave w owns image w, MFMA tile j = rows 2j, 2j+1.
 //
-// Variants (template <W8, KS, NS>; regressor.hip picks per stage, SPSP_PATCH_VARIANT overrides):
-//   <., 1, 3>  4 waves, per-tap ring of 3 slabs, one patch buffer: 65-74 KB, two workgroups per CU.  The first form;
-//              at 32 crops a layer has no more tiles than the chip has CUs, so the partner workgroup rarely exists.
-//   <., 2, 5>  8 waves: wave pairs (w, w+4 -- the two waves of one SIMD) split every K-step in halves and exchange
-//              accumulators through LDS at the end; per-tap ring of 5 slabs.
-//   <., 2, 6>  (default) as above with a GROUPED ring -- the three slabs of a kernel row land together in one half
-//              of a 2 x 3-slab ring, one vmcnt(0) + barrier per three taps; with DB (template flag, the default for
-//              layer3 / layer4) TWO patch buffers, so the next 64-channel chunk's patch lands under the nine taps of
-//              the current one (131 / 150 KB of LDS instead of 89 / 99 KB).
-// Fragment reads are software-pipelined one tap ahead of the MFMAs in every variant (two register sets).
-// What the counters say about <false, 2, 6> alone on the chip (rocprofv3 --pmc, layer2 shape): the matrix pipe is busy
-// 25 % of the kernel; a wave is parked in s_waitcnt / s_barrier 46 % of its cycles, stalled at issue (matrix pipe taken
-// by its SIMD partner, MFMA dependencies) 33 %, issuing 21 %; LDS bank conflicts < 5 % of LDS cycles.
+// One structure (the per-tap-ring forms of the first round are gone): 8 waves; wave pairs (w, w+4 -- the two waves of
+// one SIMD) split every 64-deep K-step in halves and exchange accumulators through LDS at the end; GROUPED weight ring --
+// the three slabs of a kernel row land together in one half of a 2 x 3-slab ring, one vmcnt(0) + barrier per three
+// taps; with DB (template flag, the default for layer3 / layer4) TWO patch buffers, so the next 64-channel chunk's
+// patch lands under the nine taps of the current one (131 / 150 KB of LDS instead of 89 / 99 KB).
+// Inside a tap the 8 fragment reads of the NEXT tap are issued between the first MFMA pairs of the current one (two
+// register sets, every position pinned by sched_barrier): hipcc otherwise gathers the reads in front and sinks the
+// register-only MFMAs below the lgkmcnt wait, so that a wave waits for reads it has just issued (round 1 ran that way:
+// ~65 % matrix-pipe issue inside the loop).
+// Tile order: the 8 XCDs form an XM x XN grid over (pixel tiles) x (64-channel blocks), every XCD walks its rectangle
+// channel-block-fastest -- the channel blocks that share an input patch run on ONE XCD at the same time (one L2 fill
+// instead of N/64), and each XCD's L2 holds 1/XN of the weights.  The host picks XN per layer (fewest fabric bytes).
 #include <cstdlib>
 #include <type_traits>
 
@@ -76,9 +75,9 @@ constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
 template <bool W8>
 __device__ __forceinline__ int patch_swz(int q) { return W8 ? ((q >> 1) & 7) : (q & 7); }
 
-template <bool W8, int KS, int NS>
+template <bool W8>
 struct Geo {
-    static constexpr int NW = 4 * KS;                             // waves per workgroup
+    static constexpr int NW = 8;                                  // waves per workgroup
     static constexpr int PW = W8 ? 10 : 18;                       // patch row pitch in pixels
     static constexpr int NPIX = W8 ? 400 : 324;                   // patch pixels
     static constexpr int NDMA = (NPIX + 7) / 8;                   // 8 pixels per wave-instruction
@@ -86,11 +85,11 @@ struct Geo {
     static constexpr int DPW = (NDMA + NW - 1) / NW;              // patch DMA instructions per wave
 };
 
-// One workgroup: 256 pixels x 64 channels.  grid = (M/256) * (N/64) (XCD-contiguous order).
-template <bool W8, int KS, int NS, bool F16, bool DB>
-__global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs a) {
-    using G = Geo<W8, KS, NS>;
-    constexpr int PW = G::PW, kNS = NS, NW = G::NW;
+// One workgroup: 256 pixels x 64 channels.  grid = (M/256) * (N/64).
+template <bool W8, bool F16, bool DB>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
+    using G = Geo<W8>;
+    constexpr int PW = G::PW, kNS = 6, NW = G::NW, KS = 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const ring = smem;                              // kNS x 8 KB weight stages
     unsigned char* const patch0 = smem + kNS * kWStage;            // the patch
@@ -100,11 +99,22 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     const int wave = wave_id & 3;                                  // which 64 pixels of the tile
     const int kw = wave_id >> 2;                                   // KS == 2: which 32-deep half of every K-step
     const int W = a.Wo;                                            // == Ho, == input W (stride 1)
-    const int mt = a.M / 256;
-    const int ntiles = mt * (a.N / 64);
-    int tile = blockIdx.x;
-    if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-    const int m_tile = tile % mt, n_blk = (tile / mt) * 64;
+    const int mt = a.M / 256, nb = a.N / 64;
+    int m_tile, n_blk;
+    {
+        // blocks b, b+8, b+16 ... share an XCD (round-robin dispatch; a speed assumption only): XCD x = b & 7 owns the
+        // rectangle (x / XN, x % XN) of the XM x XN grid and walks it channel-block-fastest
+        const int XN = a.xcd_n, XM = 8 / XN;
+        const int bid = blockIdx.x;
+        if (XN > 0 && mt % XM == 0 && nb % XN == 0) {
+            const int x = bid & 7, li = bid >> 3, nbl = nb / XN;
+            m_tile = (x / XN) * (mt / XM) + li / nbl;
+            n_blk = ((x % XN) * nbl + li % nbl) * 64;
+        } else {
+            m_tile = bid / nb;
+            n_blk = (bid % nb) * 64;
+        }
+    }
 
     // tile origin in the padded input (element offset of patch pixel (0,0), channel 0)
     int img0, y0 = 0, x0 = 0;
@@ -115,11 +125,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         const int t = m_tile - img0 * tpi;
         y0 = (t / tpr) * 16; x0 = (t % tpr) * 16;
     }
-    // split-K over workgroups (deep, tile-starved layers): blockIdx.y takes chunks [ch0, ch0 + nchunks) of a.chunks and
-    // leaves its fp32 partial tile in slab blockIdx.y of a.part; splitk_epilogue_kernel (conv_ring.hip) finishes.
-    const int nch_tot = a.chunks;                                  // Cin / 64
-    const int nchunks = a.splitk > 1 ? nch_tot / a.splitk : nch_tot;
-    const int ch0 = a.splitk > 1 ? (int)blockIdx.y * nchunks : 0;
+    const int nch_tot = a.chunks, nchunks = a.chunks, ch0 = 0;     // Cin / 64
     const uint16_t* const in_ptr = a.in;                           // scalar copies (keep the kernarg struct out of lambdas)
     const uint16_t* const w_ptr = a.w;
     const int Ktot = a.nsteps * 64;                                // 9 * Cin
@@ -193,56 +199,46 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     // matrix is stored tap-major/chunk-minor like the implicit-GEMM kernels, so step (ch, tap) reads K-step
     // g = tap * nchunks + ch.
     const int nsteps = 9 * nchunks;
-    constexpr int NK = 2 / KS;                          // 32-deep k-substeps this wave does per step
 
-    // ---- software pipeline: the fragment reads of step s are issued BEFORE the MFMAs of step s-1, so the LDS
-    // latency (measured: ~380 cycles per step, as much as the MFMAs themselves) hides under the matrix pipe.  Two
-    // register sets alternate; a step's set is static because the tap loop is fully unrolled and 9 is odd
-    // (set = (9 ch + tap) & 1).  Per step s:
-    //   lgkmcnt(0)            fragments of step s-1 have arrived (which also frees the ring slot / patch they came from)
-    //   vmcnt(..) + barrier   weight stage s has landed, for every wave
-    //   issue LDS-DMA         weight stage s + NS-1 into the slot of stage s-1
-    //   ds_read x (8 NK)      fragments of step s     -> set s & 1
-    //   MFMA x (16 NK)        step s-1                <- the other set
+    // ---- software pipeline: the 8 fragment reads of tap t+1 are issued between the MFMAs of tap t (two register
+    // sets; a tap's set is static because the tap loop is fully unrolled and 9 is odd: set = (9 ch + tap) & 1).
+    // Ring = 2 halves x 3 slabs.  Group g = (chunk, kernel row): at its start every wave has its own DMA pieces of
+    // group g landed (vmcnt(0): nothing younger is in flight yet); after the barrier the slabs of group g+1 are issued
+    // into the half group g-1 was read from, then the three taps run back to back -- 48 MFMAs per wave between barriers.
     // (macros, not lambdas: the fragment arrays must be indexed by literal constants to stay in registers)
-    bf16x8 wfr[2][NK][4], xfr[2][NK][4];
-#define SPSP_READ_FRAGS(TAP, SET, SLOT)                                                                   \
-    {                                                                                                     \
-        const uint32_t wbase_ = smem_base + (SLOT) * kWStage;                                             \
-        _Pragma("unroll") for (int kk = 0; kk < NK; ++kk) {                                               \
-            const int ks_ = KS == 2 ? kw : kk;                                                            \
-            const uint32_t wa_ = wbase_ + (w_lane ^ (ks_ * 64));                                          \
-            wfr[SET][kk][0] = lds_read_b128<0>(wa_);                                                      \
-            wfr[SET][kk][1] = lds_read_b128<2048>(wa_);                                                   \
-            wfr[SET][kk][2] = lds_read_b128<4096>(wa_);                                                   \
-            wfr[SET][kk][3] = lds_read_b128<6144>(wa_);                                                   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
-                xfr[SET][kk][j] = lds_read_b128<0>((KS == 2 ? xoff[TAP][j] : (xoff[TAP][j] ^ (kk * 64))) + pboff_); \
+    bf16x8 wfr[2][4], xfr[2][4];
+    const uint32_t w_lane_k = smem_base + (w_lane ^ (kw * 64));
+#define P_SB __builtin_amdgcn_sched_barrier(0);
+#define P_RW(SET, I, SLOT) wfr[SET][I] = lds_read_b128<(I) * 2048>(w_lane_k + (SLOT) * kWStage);
+#define P_RX(SET, J, TAP) xfr[SET][J] = lds_read_b128<0>(xoff[TAP][J] + pboff_);
+#define P_M2(S1, I, J, ON)                                                                                \
+        P_SB                                                                                              \
+        if (ON) {                                                                                         \
+            acc[I][J] = Elem<F16>::mfma(wfr[S1][I], xfr[S1][J], acc[I][J]);                               \
+            acc[I][(J) + 1] = Elem<F16>::mfma(wfr[S1][I], xfr[S1][(J) + 1], acc[I][(J) + 1]);             \
         }                                                                                                 \
-    }
-#define SPSP_MFMA_SET(SET)                                                                                \
+        P_SB
+#define SPSP_MFMA_SET(S1)                                                                                 \
     {                                                                                                     \
-        _Pragma("unroll") for (int kk = 0; kk < NK; ++kk)                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-                    acc[i][j] = Elem<F16>::mfma(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j]); \
+        P_M2(S1, 0, 0, true) P_M2(S1, 0, 2, true) P_M2(S1, 1, 0, true) P_M2(S1, 1, 2, true)               \
+        P_M2(S1, 2, 0, true) P_M2(S1, 2, 2, true) P_M2(S1, 3, 0, true) P_M2(S1, 3, 2, true)               \
     }
-    // wait until weight stage s has landed: `ahead` younger stages (LPS pieces each) may stay in flight
-    auto wait_stage = [&](int ahead) {
-        if (ahead >= 3 && kNS >= 5) wait_vmcnt<3 * LPS>();
-        else if (ahead == 2 && kNS >= 4) wait_vmcnt<2 * LPS>();
-        else if (ahead >= 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-    };
+    // one tap: reads of tap TAP (-> set SET, weight slab SLOT) inside the MFMAs of the previous tap (set SET^1; none if FIRST)
+#define SPSP_GTAP(TAP, SET, SLOT, FIRST)                                                                  \
+    {                                                                                                     \
+        P_RW(SET, 0, SLOT) P_RW(SET, 1, SLOT) P_M2((SET) ^ 1, 0, 0, !(FIRST))                             \
+        P_RW(SET, 2, SLOT) P_RW(SET, 3, SLOT) P_M2((SET) ^ 1, 0, 2, !(FIRST))                             \
+        P_RX(SET, 0, TAP) P_RX(SET, 1, TAP) P_M2((SET) ^ 1, 1, 0, !(FIRST))                               \
+        P_RX(SET, 2, TAP) P_RX(SET, 3, TAP) P_M2((SET) ^ 1, 1, 2, !(FIRST))                               \
+        P_M2((SET) ^ 1, 2, 0, !(FIRST)) P_M2((SET) ^ 1, 2, 2, !(FIRST))                                   \
+        P_M2((SET) ^ 1, 3, 0, !(FIRST)) P_M2((SET) ^ 1, 3, 2, !(FIRST))                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        P_SB                                                                                              \
+    }
 
     CSTAMP(0);
     issue_patch(0);
-    if constexpr (kNS == 6) {
-        // ---- grouped ring: the three slabs of one kernel row land together, ONE barrier per three K-steps ----------
-        // Ring = 2 halves x 3 slabs.  Group g = (chunk, kernel row): at its start every wave has the fragments of the
-        // previous group in registers (lgkmcnt(0)) and its own DMA pieces of group g landed (vmcnt(0): nothing younger
-        // is in flight yet); after the barrier the slabs of group g+1 are issued into the half group g-1 was read
-        // from, then the three taps run back to back -- 48 MFMAs per wave between barriers instead of 16.
+    {
         const int ngroups = 3 * nchunks;
         auto issue_group = [&](int g) {
             const int gch = g / 3, gr = g - gch * 3;
@@ -250,14 +246,6 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
             for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nch_tot + ch0 + gch, (g & 1) * 3 + t);
         };
         issue_group(0);
-#define SPSP_GTAP(TAP, SET, SLOT, FIRST)                                                                  \
-    {                                                                                                     \
-        SPSP_READ_FRAGS(TAP, SET, SLOT)                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        if (!(FIRST)) SPSP_MFMA_SET((SET) ^ 1)                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-    }
 #define SPSP_GROUP(R, P0, CH, HALF)                                                                       \
     {                                                                                                     \
         const int g_ = (CH) * 3 + (R);                                                                    \
@@ -289,65 +277,17 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
             if (ch + 1 < nchunks) { SPSP_GROUP(0, 1, ch + 1, 1) SPSP_GROUP(1, 1, ch + 1, 0) SPSP_GROUP(2, 1, ch + 1, 1) }
         }
 #undef SPSP_GROUP
-#undef SPSP_GTAP
-    } else {
-    constexpr uint32_t pboff_ = 0;
-    int issued = 0;
-    for (; issued < kNS - 1 && issued < nsteps; ++issued) issue_w((issued % 9) * nch_tot + ch0 + issued / 9, issued);
-    auto issue_next = [&]() {
-        if (issued < nsteps) {
-            const int ich = issued / 9, itap = issued - ich * 9;
-            issue_w(itap * nch_tot + ch0 + ich, issued % kNS);
-            ++issued;
-        }
-    };
-
-#define SPSP_STEP(TAP, SET, CH, S)                                                                        \
-    {                                                                                                     \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        wait_stage(min(issued - ((S) + 1), kNS - 2));                                                     \
-        __builtin_amdgcn_s_barrier();                                                                     \
-        if ((TAP) == 0 && (CH) > 0) {                                                                     \
-            /* chunk boundary: every wave is past its last read of the old patch.  Refill it; the MFMAs of the */ \
-            /* previous step run while it is in flight (patch pieces are older than the stage issued after).  */ \
-            issue_patch(CH);                                                                              \
-            issue_next();                                                                                 \
-            SPSP_MFMA_SET((SET) ^ 1)                                                                      \
-            if (issued - ((S) + 1) >= 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();                         \
-            __builtin_amdgcn_s_barrier();                                                                 \
-            SPSP_READ_FRAGS(TAP, SET, (S) % kNS)                                                          \
-        } else {                                                                                          \
-            issue_next();                                                                                 \
-            SPSP_READ_FRAGS(TAP, SET, (S) % kNS)                                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                            \
-            if ((TAP) > 0 || (S) > 0) SPSP_MFMA_SET((SET) ^ 1)                                            \
-        }                                                                                                 \
     }
-#define SPSP_CHUNK(P0, CH)                                                                                \
-    {                                                                                                     \
-        const int s0_ = (CH) * 9;                                                                         \
-        SPSP_STEP(0, (0 + P0) & 1, CH, s0_ + 0) SPSP_STEP(1, (1 + P0) & 1, CH, s0_ + 1)                    \
-        SPSP_STEP(2, (2 + P0) & 1, CH, s0_ + 2) SPSP_STEP(3, (3 + P0) & 1, CH, s0_ + 3)                    \
-        SPSP_STEP(4, (4 + P0) & 1, CH, s0_ + 4) SPSP_STEP(5, (5 + P0) & 1, CH, s0_ + 5)                    \
-        SPSP_STEP(6, (6 + P0) & 1, CH, s0_ + 6) SPSP_STEP(7, (7 + P0) & 1, CH, s0_ + 7)                    \
-        SPSP_STEP(8, (8 + P0) & 1, CH, s0_ + 8)                                                            \
-    }
-    for (int ch = 0; ch < nchunks; ch += 2) {
-        SPSP_CHUNK(0, ch)
-        if (ch + 1 < nchunks) SPSP_CHUNK(1, ch + 1)
-    }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
     if ((nsteps - 1) & 1) SPSP_MFMA_SET(1) else SPSP_MFMA_SET(0)
-#undef SPSP_CHUNK
-#undef SPSP_STEP
+#undef SPSP_GTAP
 #undef SPSP_MFMA_SET
-#undef SPSP_READ_FRAGS
+#undef P_M2
+#undef P_RX
+#undef P_RW
+#undef P_SB
 
     CSTAMP(4);
-    if constexpr (KS == 2) {
+    {
         // Combine the two K-halves: wave (kw, w) keeps channel tiles i = 2kw, 2kw+1 and hands the other two to its
         // partner through LDS (ring + patch are dead by now; 8 waves x 8 KB).  Static register indices only.
         __syncthreads();
@@ -382,26 +322,6 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     //   E  output tile    LDS -> global   (16 B per lane, whole lines)
     // LDS tiles are [256 px][128 B] with the 16-byte chunk XOR-swizzled by the pixel (bank-conflict-free both ways).
     // tile pixel tp = wave*64 + j*16 + frow.
-    if (a.splitk > 1) {
-        // partial tile -> slab [blockIdx.y][m][n] (m = linear pixel index); a lane's 4 channels are one 16-byte store
-        float* const slab = a.part + (size_t)blockIdx.y * a.M * a.N;
-        auto put_slab = [&](auto I0c) {
-            constexpr int I0 = decltype(I0c)::value, NI = 4 / KS;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tp = wave * 64 + j * 16 + frow;
-                size_t m;
-                if constexpr (W8) m = (size_t)m_tile * 256 + tp;
-                else m = ((size_t)img0 * W + (y0 + (tp >> 4))) * W + (x0 + (tp & 15));
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    *reinterpret_cast<f32x4*>(slab + m * a.N + n_blk + (I0 + i) * 16 + fq * 4) = acc[I0 + i][j];
-            }
-        };
-        if constexpr (KS == 1) put_slab(std::integral_constant<int, 0>{});
-        else { if (kw == 0) put_slab(std::integral_constant<int, 0>{}); else put_slab(std::integral_constant<int, 2>{}); }
-        return;
-    }
     __syncthreads();                                   // ring / patch / exchange buffers are dead from here on
     unsigned char* const resT = smem;
     unsigned char* const outT = smem + 256 * 128;
@@ -409,7 +329,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + (tp >> 6)) * a.out_img + (size_t)((tp >> 3) & 7) * a.out_row + (size_t)(tp & 7) * a.out_pix;
         else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
     };
-    constexpr int NTHR = 256 * KS;
+    constexpr int NTHR = 512;
     if (a.res) {
 #pragma unroll
         for (int it = 0; it < 2048 / NTHR; ++it) {
@@ -420,7 +340,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         __syncthreads();
     }
     auto epilogue = [&](auto I0c) {
-        constexpr int I0 = decltype(I0c)::value, NI = 4 / KS;
+        constexpr int I0 = decltype(I0c)::value, NI = 2;
         float psum[NI][4];
 #pragma unroll
         for (int i = 0; i < NI; ++i) psum[i][0] = psum[i][1] = psum[i][2] = psum[i][3] = 0.f;
@@ -459,8 +379,7 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
         }
     };
     CSTAMP(5);
-    if constexpr (KS == 1) epilogue(std::integral_constant<int, 0>{});
-    else { if (kw == 0) epilogue(std::integral_constant<int, 0>{}); else epilogue(std::integral_constant<int, 2>{}); }
+    if (kw == 0) epilogue(std::integral_constant<int, 0>{}); else epilogue(std::integral_constant<int, 2>{});
     if (a.out) {
         __syncthreads();
 #pragma unroll
@@ -473,34 +392,35 @@ __global__ __launch_bounds__(256 * KS) void conv3x3_patch_kernel(const ConvArgs 
     CSTAMP(6);
 }
 
-template <bool W8, int KS, int NS, bool F16, bool DB>
+template <bool W8, bool F16, bool DB>
 int launch_t(const ConvArgs& a, hipStream_t st) {
-    using G = Geo<W8, KS, NS>;
-    constexpr size_t lds = (size_t)NS * kWStage + (DB ? 2 : 1) * G::PATCH;
+    using G = Geo<W8>;
+    constexpr size_t lds = (size_t)6 * kWStage + (DB ? 2 : 1) * G::PATCH;
     static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
-    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, KS, NS, F16, DB>>((int)lds)));
+    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB>>((int)lds)));
+    const int grid = (a.M / 256) * (a.N / 64);
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
         (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_patch_kernel<W8, KS, NS, F16, DB><<<dim3((a.M / 256) * (a.N / 64)), 256 * KS, lds, st>>>(b);
+        conv3x3_patch_kernel<W8, F16, DB><<<dim3(grid), 512, lds, st>>>(b);
         (void)hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "patch<W8=%d,KS=%d,NS=%d> chunks=%d wgs=%d: K loop %llu | K-half exchange + residual staging %llu | epilogue + stores %llu | total %llu cycles\n",
-                (int)W8, KS, NS, a.chunks, (a.M / 256) * (a.N / 64), h[4] - h[0], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        fprintf(stderr, "patch<W8=%d,DB=%d> chunks=%d wgs=%d: K loop %llu | K-half exchange + residual staging %llu | epilogue + stores %llu | total %llu cycles\n",
+                (int)W8, (int)DB, a.chunks, grid, h[4] - h[0], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
         (void)hipFree(b.dbg);
         return SPSP_OK;
     }
 #endif
-    conv3x3_patch_kernel<W8, KS, NS, F16, DB><<<dim3((a.M / 256) * (a.N / 64), a.splitk > 1 ? a.splitk : 1), 256 * KS, lds, st>>>(a);
+    conv3x3_patch_kernel<W8, F16, DB><<<dim3(grid), 512, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
 
-template <bool W8, int KS, int NS, bool DB = false>
+template <bool W8, bool DB>
 int launch(const ConvArgs& a, hipStream_t st) {
-    return a.f16 ? launch_t<W8, KS, NS, true, DB>(a, st) : launch_t<W8, KS, NS, false, DB>(a, st);
+    return a.f16 ? launch_t<W8, true, DB>(a, st) : launch_t<W8, false, DB>(a, st);
 }
 
 }  // namespace
@@ -509,20 +429,33 @@ namespace spsp {
 
 bool conv_patch_supported(const ConvArgs& a) {
     return a.stride == 1 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && a.in_off == 0 && a.M % 256 == 0 && a.N % 64 == 0 &&
-           a.Ho == a.Wo && (a.Wo == 8 || a.Wo % 16 == 0) && (a.splitk <= 1 || (a.part && a.chunks % a.splitk == 0));
+           a.Ho == a.Wo && (a.Wo == 8 || a.Wo % 16 == 0) && a.splitk <= 1;
 }
 
-int launch_conv_patch(const ConvArgs& a, int variant, hipStream_t stream) {
-    SPSP_REQUIRE(conv_patch_supported(a), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
-    SPSP_REQUIRE(!a.pool_out || a.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
-    // variant 0: 4 waves, ring 3 (65-74 KB LDS: two workgroups per CU) -- many-workgroup layers
-    // variant 1: 8 waves (wave pairs split each K-step), ring 5 -- few-workgroup deep layers, one workgroup per CU
-    // variant 3: 8 waves, grouped ring of 2 x 3 slabs -- one barrier per kernel row (three K-steps)
-    // variant 4: 3 with TWO patch buffers (the next chunk's patch lands under the current chunk's taps; 131 / 150 KB)
-    if (a.Wo == 8) return variant == 0 ? launch<true, 1, 3>(a, stream) : variant == 3 ? launch<true, 2, 6>(a, stream) :
-                          variant == 4 ? launch<true, 2, 6, true>(a, stream) : launch<true, 2, 5>(a, stream);
-    return variant == 0 ? launch<false, 1, 3>(a, stream) : variant == 3 ? launch<false, 2, 6>(a, stream) :
-           variant == 4 ? launch<false, 2, 6, true>(a, stream) : launch<false, 2, 5>(a, stream);
+// How the 8 XCDs are laid over the (pixel tiles) x (channel blocks) grid: XN of them along the channel blocks.  An XCD
+// pulls its share of the weights (1 / XN) and of the input (XN / 8) through the fabric into its own L2; the split with
+// the fewest bytes wins (layer2: 8 x 1, layer4: 2 x 4).
+int conv_patch_xcd_n(const ConvArgs& a) {
+    const int mt = a.M / 256, nb = a.N / 64;
+    const double wbytes = (double)a.N * a.nsteps * 64 * 2, xbytes = (double)a.M * a.chunks * 64 * 2;
+    int best = 0;
+    double best_b = 0;
+    for (int xn = 1; xn <= 8; xn *= 2) {
+        const int xm = 8 / xn;
+        if (nb % xn || mt % xm) continue;
+        const double bytes = 8.0 * (wbytes / xn + xbytes / xm);
+        if (!best || bytes < best_b) { best = xn; best_b = bytes; }
+    }
+    return best;      // 0: no split fits (the kernel falls back to channel-block-fastest over the whole grid)
+}
+
+int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, hipStream_t stream) {
+    SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
+    SPSP_REQUIRE(!a0.pool_out || a0.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
+    ConvArgs a = a0;
+    a.xcd_n = conv_patch_xcd_n(a);
+    if (a.Wo == 8) return two_patch_buffers ? launch<true, true>(a, stream) : launch<true, false>(a, stream);
+    return two_patch_buffers ? launch<false, true>(a, stream) : launch<false, false>(a, stream);
 }
 
 }  // namespace spsp

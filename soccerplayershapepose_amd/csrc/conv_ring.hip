@@ -1,7 +1,7 @@
 // Implicit-GEMM convolution, second generation: NS-stage LDS ring filled by LDS-DMA
 // (global_load_lds_dwordx4: HBM/L2 -> LDS with no VGPR round trip), counted vmcnt waits, ONE raw s_barrier per
 // K-step, fragment reads by inline-asm ds_read_b128 (hipcc would otherwise drain vmcnt(0) in front of every
-// ds_read that might alias an in-flight LDS-DMA), optional split-K with fp32 slabs.
+// ds_read that might alias an in-flight LDS-DMA).
 //
 // Why: at 32 crops the deep layers have only 256 workgroups (one per CU, one wave per SIMD); with a single
 // prefetch stage every K-step exposes a full L2/MALL round trip.  A ring keeps NS-1 K-steps of loads in flight
@@ -39,7 +39,7 @@ __device__ __forceinline__ void dma16(const uint16_t* gsrc, unsigned char* lds_w
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NS, bool SPLITK, bool F16>
+template <int BM, int BN, int NS, bool F16>
 __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     constexpr int BK = 64, ROWB = 128;
     constexpr int STAGE = (BM + BN) * ROWB;
@@ -56,20 +56,20 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     const int HoWo = a.Ho * a.Wo;
 
     // tile order: XCD-contiguous (see conv.hip)
-    const int mt = a.M / BM;
-    const int ntiles = mt * (a.N / BN);
+    const int mt = a.M / BM, nb1 = a.N / BN;
+    const int ntiles = mt * (nb1 + a.n2 / BN);
     int tile = blockIdx.x;
     if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-    const int m_blk = (tile % mt) * BM, n_blk = (tile / mt) * BN;
-
-    // K range of this workgroup (split-K over blockIdx.y)
-    int step_lo = 0, step_hi = a.nsteps;
-    if constexpr (SPLITK) {
-        const int per = (a.nsteps + a.splitk - 1) / a.splitk;
-        step_lo = blockIdx.y * per;
-        step_hi = min(a.nsteps, step_lo + per);
-    }
-    const int nsteps = step_hi - step_lo;
+    const int m_blk = (tile % mt) * BM;
+    // channel blocks past N belong to the second convolution (the 1x1 downsample): only the centre-tap K-steps
+    const bool second = tile / mt >= nb1;
+    const int n_blk = (tile / mt - (second ? nb1 : 0)) * BN;
+    const int step_lo = second ? 4 * a.chunks : 0, nsteps = second ? a.chunks : a.nsteps;
+    const uint16_t* const w_ptr = second ? a.w2 : a.w;
+    const float* const bias_ptr = second ? a.bias2 : a.bias;
+    uint16_t* const out_ptr = second ? a.out2 : a.out;
+    const uint16_t* const res_ptr = second ? nullptr : a.res;
+    const int relu = second ? 0 : a.relu;
 
     // ---- LDS-DMA sources: lane l of instruction i feeds LDS row (wave*ROWS/4 + i*8 + l/8), physical chunk l%8,
     //      i.e. logical chunk (l%8) ^ (row%8) of that row ----
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
         a_src[i] = a.in + a.in_off + (size_t)b * a.in_img + ho * a.stride * a.in_row + wo * a.stride * a.in_pix +
                    ((dchunk ^ (row & 7)) * 8);
     }
-    const int Ktot = a.nsteps * BK;
+    const int Ktot = nsteps * BK;
     const uint16_t* b_src[IB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
         const int row = wave * (BN / 4) + i * 8 + drow;
-        b_src[i] = a.w + (size_t)(n_blk + row) * Ktot + ((dchunk ^ (row & 7)) * 8);
+        b_src[i] = w_ptr + (size_t)(n_blk + row) * Ktot + ((dchunk ^ (row & 7)) * 8) - (size_t)step_lo * BK;   // indexed by the 3x3's step number
     }
     const int in_row = a.in_row, in_pix = a.in_pix, kw_steps = a.kw_steps, chunks = a.chunks;
 
@@ -159,20 +159,7 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue ----
-    if constexpr (SPLITK) {
-        // fp32 slab [split][M][N]: lane writes 4 consecutive channels (16 B) of one pixel
-        float* slab = a.part + (size_t)blockIdx.y * a.M * a.N;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = m_blk + wm * (BM / 2) + j * 16 + frow;
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int n = n_blk + wn * (BN / 2) + i * 16 + fq * 4;
-                *reinterpret_cast<float4*>(slab + (size_t)m * a.N + n) =
-                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            }
-        }
-    } else {
+    {
         float psum[NT][4];
 #pragma unroll
         for (int i = 0; i < NT; ++i) psum[i][0] = psum[i][1] = psum[i][2] = psum[i][3] = 0.f;
@@ -184,14 +171,14 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int n = n_blk + wn * (BN / 2) + i * 16 + fq * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                const float4 bv = *reinterpret_cast<const float4*>(bias_ptr + n);
                 float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-                if (a.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
+                if (res_ptr) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(res_ptr + obase + n);
                     v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
                 }
-                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (out_ptr) *reinterpret_cast<uint2*>(out_ptr + obase + n) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
                 psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
             }
         }
@@ -215,71 +202,17 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     }
 }
 
-// Split-K second pass: out = act(sum_s slab[s] + bias (+ residual)) as bf16 NHWC (+ fused global avg-pool).
-// One thread per (pixel, 4 channels); for the pooled layer a workgroup covers whole images.
-template <bool F16>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) {
-    const int n4 = a.N / 4;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)a.M * n4;
-    if (idx >= total) return;
-    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
-    const size_t MN = (size_t)a.M * a.N;
-    float4 v = *reinterpret_cast<const float4*>(a.part + (size_t)m * a.N + n);
-    for (int s = 1; s < a.splitk; ++s) {
-        const float4 p = *reinterpret_cast<const float4*>(a.part + s * MN + (size_t)m * a.N + n);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-    }
-    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    const int HoWo = a.Ho * a.Wo;
-    const int b = m / HoWo, rem = m - b * HoWo, ho = rem / a.Wo, wo = rem - ho * a.Wo;
-    const size_t obase = (size_t)a.out_off + (size_t)b * a.out_img + (size_t)ho * a.out_row + (size_t)wo * a.out_pix;
-    if (a.res) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(a.res + obase + n);
-        v.x += Elem<F16>::lo(rv.x); v.y += Elem<F16>::hi(rv.x); v.z += Elem<F16>::lo(rv.y); v.w += Elem<F16>::hi(rv.y);
-    }
-    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (a.out) *reinterpret_cast<uint2*>(a.out + obase + n) = make_uint2(Elem<F16>::pack2(v.x, v.y), Elem<F16>::pack2(v.z, v.w));
-    if (a.pool_out) {
-        // fp32 values kept for the pool pass in slab 0 (overwrites this thread's own input element only)
-        *reinterpret_cast<float4*>(a.part + (size_t)m * a.N + n) = v;
-    }
-}
-
-// Global average pool over the fp32 post-activation values left in slab 0 by splitk_epilogue_kernel.
-__global__ void pool_from_slab_kernel(const float* __restrict__ slab, int HoWo, int N, float* __restrict__ out) {
-    const int b = blockIdx.x;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < HoWo; ++p) s += slab[((size_t)b * HoWo + p) * N + n];
-        out[(size_t)b * N + n] = s / (float)HoWo;
-    }
-}
-
 template <int BM, int BN, int NS, bool F16>
 int launch_t(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(a.N % BN == 0 && a.M % BM == 0, "conv_ring: M=%d N=%d not multiples of the %dx%d tile", a.M, a.N, BM, BN);
     SPSP_REQUIRE(a.in_pix % 8 == 0 && a.in_off % 8 == 0 && a.in_row % 8 == 0, "conv_ring: input not 16-byte aligned");
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-    const int tiles = (a.M / BM) * (a.N / BN);
-    if (a.splitk > 1) {
-        SPSP_REQUIRE(a.part != nullptr, "conv_ring: split-K needs a slab workspace");
-        SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, true, F16>>((int)lds)));
-        conv_ring_kernel<BM, BN, NS, true, F16><<<dim3(tiles, a.splitk), 256, lds, st>>>(a);
-        SPSP_HIP_CHECK(hipGetLastError());
-        const size_t total = (size_t)a.M * (a.N / 4);
-        splitk_epilogue_kernel<F16><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
-        SPSP_HIP_CHECK(hipGetLastError());
-        if (a.pool_out) {
-            pool_from_slab_kernel<<<a.M / (a.Ho * a.Wo), 256, 0, st>>>(a.part, a.Ho * a.Wo, a.N, a.pool_out);
-            SPSP_HIP_CHECK(hipGetLastError());
-        }
-        return SPSP_OK;
-    }
+    SPSP_REQUIRE(a.n2 == 0 || (a.n2 % BN == 0 && a.w2 && a.bias2 && a.out2 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && !a.pool_out),
+                 "conv_ring: the second convolution must be a 1x1 riding on a 3x3 (n2 %% %d == 0)", BN);
+    const int tiles = (a.M / BM) * (a.N / BN + a.n2 / BN);
     SPSP_REQUIRE(!a.pool_out || BM == a.Ho * a.Wo, "conv_ring: fused avg-pool needs one image per M tile");
-    SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, false, F16>>((int)lds)));
-    conv_ring_kernel<BM, BN, NS, false, F16><<<dim3(tiles, 1), 256, lds, st>>>(a);
+    SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, F16>>((int)lds)));
+    conv_ring_kernel<BM, BN, NS, F16><<<dim3(tiles), 256, lds, st>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
@@ -292,19 +225,6 @@ int launch(const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 namespace spsp {
-
-int launch_splitk_epilogue(const ConvArgs& a, hipStream_t st) {
-    SPSP_REQUIRE(a.splitk > 1 && a.part, "splitk_epilogue: no slabs");
-    const size_t total = (size_t)a.M * (a.N / 4);
-    if (a.f16) splitk_epilogue_kernel<true><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
-    else splitk_epilogue_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
-    SPSP_HIP_CHECK(hipGetLastError());
-    if (a.pool_out) {
-        pool_from_slab_kernel<<<a.M / (a.Ho * a.Wo), 256, 0, st>>>(a.part, a.Ho * a.Wo, a.N, a.pool_out);
-        SPSP_HIP_CHECK(hipGetLastError());
-    }
-    return SPSP_OK;
-}
 
 int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream) {
     switch (tile) {

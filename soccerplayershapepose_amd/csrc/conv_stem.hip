@@ -1,0 +1,346 @@
+// The stem of the backbone in ONE kernel: conv1 (7x7 / stride 2 / pad 3, 18 -> 64 channels, 256x256 -> 128x128)
+// + folded BN bias + ReLU + max-pool 3x3 / stride 2 / pad 1 (-> 64x64)   (PR/models/resnet.py:145-149, 203-207).
+//
+// Why a new structure.  The previous stem (conv1_half_kernel + maxpool_kernel, 64 + 21 us at 32 crops) was bound by
+// the L2 -> LDS fill path: every workgroup re-streamed the 114 KB weight matrix next to its input patch (362 MB of
+// LDS-DMA per launch against 80 MB of input), then wrote the 128x128x64 map (69 MB) only for the pool kernel to read it
+// back (102 MB with halos) and write 17.8 MB.  Here
+//   * the WEIGHTS LIVE IN REGISTERS: a wave owns 32 output channels and keeps their whole [32 x 896] weight slice as MFMA
+//     A-fragments (2 x 28 fragments = 224 VGPRs, loaded once; one wave per SIMD has 512 registers).  No weight traffic
+//     and no weight LDS reads in the loop: a 32-deep sub-step reads 8 pixel fragments for 16 MFMAs;
+//   * the INPUT IS A ROLLING WINDOW: a persistent workgroup walks a band of conv rows two at a time; a step needs 9 input
+//     rows of which 5 are already in LDS, the 4 new ones (38 KB) arrive by LDS-DMA under the previous step's MFMAs
+//     (13-row ring, 130 KB).  L2 -> LDS traffic = the input, once (+ one halo step per band);
+//   * the POOL IS FUSED: horizontal 3 -> 1 max in registers (DPP row shifts: the 16 pixels of an MFMA tile sit in the 16
+//     lanes of a DPP row), rows exchanged through 8 KB LDS buffers, vertical max over (row 2p-1 kept from the previous
+//     step, 2p, 2p+1), whole 128-byte pixel lines to HBM.  The 128x128 map never exists.
+// Rounding: bias + ReLU + round-to-element commute with max (all monotone), so the result is bit-identical to
+// pool(round(relu(conv + bias))) -- what the unfused kernels and the oracle compute.
+//
+// Workgroup = 4 waves = (channel half h) x (conv row r of the step's two rows); wave tile = 32 ch x 128 px (one whole
+// conv row): acc[2][8] x f32x4.  K-step = kernel row (7 taps x 18 ch = 126 contiguous input values, padded to 128 by
+// two zero weights), 4 sub-steps of 32; pixel fragments are 8-byte aligned (pixel pitch 36 B): 2 x ds_read_b64 each.
+#include <cstdlib>
+
+#include "conv.hpp"
+#include "conv_elem.hpp"
+
+namespace {
+using namespace spsp;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_2xb64(uint32_t addr) {
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 8) : "memory");
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void dma16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int kRowB = 264 * 18 * 2;        // 9504 bytes of one native input row
+constexpr int kRowPieces = 10;             // 1-KiB LDS-DMA pieces per row (the last one re-reads the row's tail)
+constexpr int kPitch = kRowPieces * 1024;  // LDS row pitch
+constexpr int kRing = 13;                  // rows in the window: 9 of the current step + 4 arriving for the next
+constexpr int kRingB = kRing * kPitch;     // 133 120
+constexpr int kHRowB = 64 * 128;           // one horizontally pooled row: [64 pool px][64 ch] elements
+constexpr int kLds = kRingB + 3 * kHRowB;  // + A, B[2]  = 157 696
+constexpr int kWBytes = 64 * 896 * 2;      // the weight matrix, 114 688 B = 112 LDS-DMA pieces
+constexpr int kWOff = 4 * kPitch;          // prologue: it passes through LDS behind ring rows 0..3 (ends at 155 648 < kLds)
+static_assert(kWOff + kWBytes <= kLds, "weight staging must fit behind the first four ring rows");
+
+// DPP row controls (a DPP row = 16 lanes = the 16 pixels of one MFMA tile)
+constexpr int kDppShl1 = 0x101;            // lane l <- lane l+1
+constexpr int kDppShr1 = 0x111;            // lane l <- lane l-1
+constexpr int kDppRor1 = 0x121;            // lane l <- lane (l-1) mod 16
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src) {      // lanes without a source lane keep `old`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y)));
+}
+
+#ifdef SPSP_CONV_STAMPS
+#define SSTAMP(i) if (a.dbg && blockIdx.x == 9 && tid == 0 && st == 3) a.dbg[i] = __builtin_amdgcn_s_memtime()
+#define SSTAMPK(i) if (a.dbg && blockIdx.x == 9 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
+#else
+#define SSTAMP(i)
+#define SSTAMPK(i)
+#endif
+
+struct StemArgs {
+    const uint16_t* in;      // native [B][262][264][18]
+    const uint16_t* w;       // [64][7*128], K = kernel row * 128 + tap * 18 + channel (+ 2 zero pads per row)
+    const float* bias;       // [64]
+    uint16_t* out;           // [B][66][66][64]: pooled map with a 1-px zero border (interior written here)
+    int bands;               // bands per image
+    int rows_per_band;       // conv rows per band: 16, 8 or 4 (a band = rows_per_band / 2 pool rows)
+    unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of one workgroup
+};
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    unsigned char* const hA = smem + kRingB;                  // pooled conv row 2s   (wave row 0)
+    unsigned char* const hB = smem + kRingB + kHRowB;         // pooled conv row 2s+1 (wave row 1), two parities
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SSTAMPK(0);
+    const int h = wave & 1, r = wave >> 1;                    // channel half, conv row within the step
+    const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
+    const int RB = a.rows_per_band;
+    const int s0 = band > 0 ? -1 : 0;                         // the halo step: conv rows band*RB-2, band*RB-1 (only the carry row is kept)
+    const int nsteps = RB / 2 - s0;
+    const int first_row = 2 * (band * RB + 2 * s0);           // native input row of ring row 0
+    const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * (262 * kRowB) + (size_t)first_row * kRowB;
+
+    // ---- LDS-DMA of one input row (relative index n) into its ring slot: 10 pieces, tail lanes re-read the last 16 bytes
+    const int lane_src = lane * 16;
+    auto issue_row = [&](int n) {
+        const unsigned char* src = in_b + (size_t)n * kRowB;
+        unsigned char* dst = smem + (n % kRing) * kPitch;
+#pragma unroll
+        for (int p = 0; p < kRowPieces; ++p) {
+            int o = p * 1024 + lane_src;
+            o = o < kRowB - 16 ? o : kRowB - 16;
+            dma16(src + o, dst + p * 1024);
+        }
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    // ---- prologue.  The weights reach the registers THROUGH LDS: fetched straight from global as fragments they are 64-byte
+    // segments of 16 rows per instruction, twice per workgroup (measured: 21.8 k cycles of prologue with every CU doing it at
+    // once).  Here the 114 KB matrix is ONE linear LDS-DMA copy (112 whole-line pieces) into the part of LDS the first four
+    // input rows do not use, every wave then picks its 56 fragments with conflict-free ds_read_b128 (rows are 1792 B = 7 bank
+    // rows apart, so the 16-byte chunk index is XORed with the row's low 4 bits -- on the DMA source, and on the read), and
+    // the remaining five rows of the first step are fetched behind it.
+    issue_row(wave);                                          // ring rows 0..3
+    {
+        const unsigned char* const wb = reinterpret_cast<const unsigned char*>(a.w);
+        for (int p = wave; p < kWBytes / 1024; p += 4) {
+            const int L = p * 64 + lane, row = L / 112, c = L - row * 112;
+            dma16(wb + (size_t)(row * 112 + (c ^ (row & 15))) * 16, smem + kWOff + p * 1024);
+        }
+    }
+    float4 bias_r[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const float4*>(a.bias + 32 * h + 16 * i + 4 * fq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- this wave's weights as MFMA A-fragments, resident for the whole kernel: row 32h + 16i + frow, chunk 4g + fq ----
+    bf16x8 wreg[2][28];
+    {
+        // chunk' = (4g + fq) ^ frow: bits 0-1 fq ^ (frow & 3), bits 2-3 (g & 3) ^ (frow >> 2), the rest g >> 2 -> one base per g & 3
+        uint32_t wa[4];
+#pragma unroll
+        for (int g3 = 0; g3 < 4; ++g3)
+            wa[g3] = smem_base + kWOff + (32 * h + frow) * 1792 + 64 * (g3 ^ (frow >> 2)) + 16 * (fq ^ (frow & 3));
+        // four fragments AND their wait in one asm statement: hipcc takes an asm output as written when the statement ends
+        // and moves most of these long-lived fragments to accumulator registers right behind it -- with the wait in a
+        // later statement it copied registers the LDS had not filled yet
+#define STEM_WR4(I, G)                                                                                    \
+        asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"                 \
+                     "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)" \
+                     : "=&v"(wreg[I][G]), "=&v"(wreg[I][(G) + 1]), "=&v"(wreg[I][(G) + 2]), "=&v"(wreg[I][(G) + 3]) \
+                     : "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "n"((I) * 16 * 1792 + ((G) >> 2) * 256) : "memory");
+        STEM_WR4(0, 0) STEM_WR4(0, 4) STEM_WR4(0, 8) STEM_WR4(0, 12) STEM_WR4(0, 16) STEM_WR4(0, 20) STEM_WR4(0, 24)
+        STEM_WR4(1, 0) STEM_WR4(1, 4) STEM_WR4(1, 8) STEM_WR4(1, 12) STEM_WR4(1, 16) STEM_WR4(1, 20) STEM_WR4(1, 24)
+#undef STEM_WR4
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                          // every wave has its fragments: the staging area is free
+    for (int n = 4 + wave; n < 9; n += 4) issue_row(n);       // ring rows 4..8
+    // the row above the image is padding: the carry of the first step of the top band is all zeros (post-ReLU values are >= 0)
+    if (s0 == 0)
+        for (int i = tid; i < kHRowB / 16; i += 256) reinterpret_cast<uint4*>(hB + kHRowB)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    const uint32_t lane_off = 72 * frow + 16 * fq;            // pixel 16j + frow starts 72 (16j + frow) bytes into the row
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SSTAMPK(1);
+
+    for (int st = 0; st < nsteps; ++st) {
+        SSTAMP(2);
+        const int s = s0 + st;                                // conv rows band*RB + 2s, + 2s + 1  ->  pool row band*RB/2 + s
+        const int n0 = 4 * st;                                // ring row index of this step's first input row
+        if (st + 1 < nsteps) issue_row(n0 + 9 + wave);        // the 4 new rows of the next step, one per wave
+
+        f32x4 acc[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // fragment base address per kernel row: input row 2 (conv row) + kr = ring row n0 + 2r + kr
+        uint32_t xa[7];
+#pragma unroll
+        for (int kr = 0; kr < 7; ++kr) xa[kr] = smem_base + (uint32_t)(((n0 + 2 * r + kr) % kRing) * kPitch) + lane_off;
+
+        bf16x8 xf[2][8];
+        // sub-step G = 4 KR + KS: 16 MFMAs on fragment set G & 1.  The eight fragment reads of sub-step G+1 (kernel row KRN,
+        // quarter KSN) go out between the first four MFMA pairs of sub-step G, so that their issue slots and most of their
+        // latency sit under the matrix pipe; every sched_barrier pins that order (hipcc otherwise gathers the reads in
+        // front and sinks the register-only MFMAs below the wait).  A deeper look-ahead is not available: a fragment is
+        // two ds_read_b64 (8-byte aligned pixels), 16 per set, and lgkmcnt counts to 15 -- a counted wait that leaves a
+        // whole set in flight cannot be written (and scalar loads share the counter and return out of order).
+#define STEM_SB __builtin_amdgcn_sched_barrier(0);
+#define STEM_RD(G, J, KRN, KSN, LAST)                                                                     \
+        if (!(LAST)) xf[((G) + 1) & 1][J] = lds_read_2xb64<64 * (KSN) + 1152 * (J)>(xa[KRN]);
+#define STEM_MM(G, J)                                                                                     \
+        STEM_SB                                                                                           \
+        acc[0][J] = Elem<F16>::mfma(wreg[0][G], xf[(G) & 1][J], acc[0][J]);                               \
+        acc[1][J] = Elem<F16>::mfma(wreg[1][G], xf[(G) & 1][J], acc[1][J]);                               \
+        STEM_SB
+#define STEM_STEP(G, KRN, KSN, LAST)                                                                      \
+    {                                                                                                     \
+        STEM_RD(G, 0, KRN, KSN, LAST) STEM_RD(G, 1, KRN, KSN, LAST) STEM_MM(G, 0)                          \
+        STEM_RD(G, 2, KRN, KSN, LAST) STEM_RD(G, 3, KRN, KSN, LAST) STEM_MM(G, 1)                          \
+        STEM_RD(G, 4, KRN, KSN, LAST) STEM_RD(G, 5, KRN, KSN, LAST) STEM_MM(G, 2)                          \
+        STEM_RD(G, 6, KRN, KSN, LAST) STEM_RD(G, 7, KRN, KSN, LAST) STEM_MM(G, 3)                          \
+        STEM_MM(G, 4) STEM_MM(G, 5) STEM_MM(G, 6) STEM_MM(G, 7)                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        STEM_SB                                                                                           \
+    }
+        xf[0][0] = lds_read_2xb64<0>(xa[0]);        xf[0][1] = lds_read_2xb64<1152>(xa[0]);
+        xf[0][2] = lds_read_2xb64<2 * 1152>(xa[0]); xf[0][3] = lds_read_2xb64<3 * 1152>(xa[0]);
+        xf[0][4] = lds_read_2xb64<4 * 1152>(xa[0]); xf[0][5] = lds_read_2xb64<5 * 1152>(xa[0]);
+        xf[0][6] = lds_read_2xb64<6 * 1152>(xa[0]); xf[0][7] = lds_read_2xb64<7 * 1152>(xa[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STEM_SB
+        //        G   sub-step G+1 = (KR, KS)
+        STEM_STEP(0, 0, 1, false)  STEM_STEP(1, 0, 2, false)  STEM_STEP(2, 0, 3, false)  STEM_STEP(3, 1, 0, false)
+        STEM_STEP(4, 1, 1, false)  STEM_STEP(5, 1, 2, false)  STEM_STEP(6, 1, 3, false)  STEM_STEP(7, 2, 0, false)
+        STEM_STEP(8, 2, 1, false)  STEM_STEP(9, 2, 2, false)  STEM_STEP(10, 2, 3, false) STEM_STEP(11, 3, 0, false)
+        STEM_STEP(12, 3, 1, false) STEM_STEP(13, 3, 2, false) STEM_STEP(14, 3, 3, false) STEM_STEP(15, 4, 0, false)
+        STEM_STEP(16, 4, 1, false) STEM_STEP(17, 4, 2, false) STEM_STEP(18, 4, 3, false) STEM_STEP(19, 5, 0, false)
+        STEM_STEP(20, 5, 1, false) STEM_STEP(21, 5, 2, false) STEM_STEP(22, 5, 3, false) STEM_STEP(23, 6, 0, false)
+        STEM_STEP(24, 6, 1, false) STEM_STEP(25, 6, 2, false) STEM_STEP(26, 6, 3, false) STEM_STEP(27, 6, 3, true)
+#undef STEM_STEP
+#undef STEM_MM
+#undef STEM_RD
+#undef STEM_SB
+
+        SSTAMP(3);
+        // ---- horizontal 3 -> 1 max in registers.  Lane (frow, fq) of tile j holds conv column 16j + frow; pool column
+        // 8j + frow/2 (even frow) = max(columns 2p-1, 2p, 2p+1) = max(left neighbour, own, right neighbour).  The right
+        // neighbour of an even lane is lane+1 of the same DPP row; the left one is lane-1, or lane 15 of tile j-1 for
+        // lane 0 (column -1 of tile 0 is padding: the lane's own value stands in).  Odd lanes compute garbage.
+        // bias + ReLU + round to the element type FIRST (all monotone: max commutes with them), so that the pool runs on 32
+        // packed registers instead of 64 floats: v_pk_max_u16 -- post-ReLU values are >= +0, and for bf16 and fp16 alike the
+        // numeric order of non-negative values is the order of their 16-bit patterns.
+        unsigned char* const hrow = r == 0 ? hA : hB + (s & 1) * kHRowB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float bv[4] = {bias_r[i].x, bias_r[i].y, bias_r[i].z, bias_r[i].w};
+            uint32_t P[8][2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 c = acc[i][j];
+                P[j][0] = Elem<F16>::pack2(fmaxf(c[0] + bv[0], 0.f), fmaxf(c[1] + bv[1], 0.f));
+                P[j][1] = Elem<F16>::pack2(fmaxf(c[2] + bv[2], 0.f), fmaxf(c[3] + bv[3], 0.f));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t m[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t v = P[j][k];
+                    const uint32_t right = dpp<kDppShl1>(v, v);
+                    const uint32_t wrap = j > 0 ? dpp<kDppRor1>(v, P[j > 0 ? j - 1 : 0][k]) : v;     // lane 0 <- lane 15 of tile j-1
+                    const uint32_t left = dpp<kDppShr1>(wrap, v);                                     // lanes 1..15 <- lane-1; lane 0 keeps `wrap`
+                    m[k] = pk_max_u16(pk_max_u16(v, right), left);
+                }
+                if (!(frow & 1)) {
+                    const int px = 8 * j + (frow >> 1);
+                    // [px][64 ch] with the 8-byte slot index XORed by 2 (px & 7): the 8 active lanes of a DPP row hit 8 bank groups
+                    const int slot = (8 * h + 4 * i + fq) ^ (2 * (px & 7));
+                    *reinterpret_cast<uint2*>(hrow + px * 128 + slot * 8) = make_uint2(m[0], m[1]);
+                }
+            }
+        }
+        SSTAMP(4);
+        // next step's rows have landed (each wave waits for its own piece), pooled rows are written: meet
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        SSTAMP(5);
+        __syncthreads();
+        SSTAMP(6);
+        if (s >= 0) {
+            // ---- vertical max over conv rows 2p-1 (carry), 2p, 2p+1 and the store of pool row p: thread -> pixel tid/4, 32 bytes
+            const int px = tid >> 2, q = tid & 3;
+            const int prow = band * (RB / 2) + s;
+            uint16_t* const orow = a.out + (size_t)b * (66 * 66 * 64) + (size_t)(prow + 1) * (66 * 64) + (size_t)(px + 1) * 64;
+            const unsigned char* const carry = hB + ((s + 1) & 1) * kHRowB;
+            const unsigned char* const cur1 = hB + (s & 1) * kHRowB;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int c = 2 * q + c2;
+                const int off = px * 128 + (((2 * c) ^ (2 * (px & 7))) * 8);
+                const uint4 va = *reinterpret_cast<const uint4*>(hA + off);
+                const uint4 vb = *reinterpret_cast<const uint4*>(cur1 + off);
+                const uint4 vc = *reinterpret_cast<const uint4*>(carry + off);
+                // post-ReLU values are >= +0: for bf16 and fp16 alike the numeric order is the order of the 16-bit patterns
+                auto mx = [](uint32_t x, uint32_t y, uint32_t z) -> uint32_t { return pk_max_u16(pk_max_u16(x, y), z); };
+                *reinterpret_cast<uint4*>(orow + c * 8) = make_uint4(mx(va.x, vb.x, vc.x), mx(va.y, vb.y, vc.y), mx(va.z, vb.z, vc.z), mx(va.w, vb.w, vc.w));
+            }
+        }
+        SSTAMP(7);
+        __syncthreads();          // hA and the carry buffer are free for the next step
+        SSTAMP(8);
+    }
+    SSTAMPK(9);
+}
+
+}  // namespace
+
+namespace spsp {
+
+// conv1 + BN + ReLU + max-pool for B crops: in = native [B][262][264][18], out = [B][66][66][64] (interior).
+int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
+                     hipStream_t st) {
+    SPSP_REQUIRE(in && w && bias && out && B > 0, "conv_stem: bad arguments");
+    StemArgs a;
+    a.in = in; a.w = w; a.bias = bias; a.out = out;
+    // bands of 16 conv rows (8 per image) fill 256 CUs at 32 crops with one halo step in nine; smaller batches take
+    // finer bands so that the grid still covers the chip
+    a.rows_per_band = B * 8 >= num_cus ? 16 : (B * 16 >= num_cus ? 8 : 4);
+    a.bands = 128 / a.rows_per_band;
+    SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<false>>(kLds));
+    SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<true>>(kLds));
+    a.dbg = nullptr;
+#ifdef SPSP_CONV_STAMPS
+    if (getenv("SPSP_CONV_DEBUG")) {
+        (void)hipMalloc(&a.dbg, 16 * sizeof(unsigned long long));
+        if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+        else conv1_pool_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+        (void)hipDeviceSynchronize();
+        unsigned long long hh[16];
+        (void)hipMemcpy(hh, a.dbg, sizeof hh, hipMemcpyDeviceToHost);
+        fprintf(stderr, "stem wg9 (band 1, 9 steps): prologue %llu | step3: K loop %llu | h-pool + LDS writes %llu | vmcnt/lgkm wait %llu | barrier %llu | vertical + stores %llu | barrier %llu | whole kernel %llu cycles\n",
+                hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
+        (void)hipFree(a.dbg);
+        return SPSP_OK;
+    }
+#endif
+    if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+    else conv1_pool_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+    SPSP_HIP_CHECK(hipGetLastError());
+    return SPSP_OK;
+}
+
+}  // namespace spsp

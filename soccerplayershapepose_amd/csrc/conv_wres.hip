@@ -194,13 +194,32 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                  \
                     acc[i][j] = Elem<F16>::mfma(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j]); \
     }
+        // One tap: the 16 fragment reads of tap TAP (set SET) go out between the 32 MFMAs of the previous tap (set SET^1),
+        // one read per MFMA pair and all of them within the first half, so that their issue slots and their latency sit
+        // under the matrix pipe.  Every sched_barrier pins that order: hipcc otherwise gathers the reads in front and sinks
+        // the register-only MFMAs BELOW the wait (measured: the wave then waits for reads it has just issued).
+#define WRES_SB __builtin_amdgcn_sched_barrier(0);
+#define WRES_RW(SET, KK, I, TAP) wfr[SET][KK][I] = lds_read_b128<(I) * 2048>(((KK) ? w_lane1 : w_lane) + (TAP) * kWSlab);
+#define WRES_RX(SET, KK, J, TAP) xfr[SET][KK][J] = lds_read_b128<0>(xoff[TAP][J] ^ ((KK) * 64));
+#define WRES_M2(S1, KK, I, J)                                                                  \
+        WRES_SB                                                                                \
+        acc[I][J] = Elem<F16>::mfma(wfr[S1][KK][I], xfr[S1][KK][J], acc[I][J]);                \
+        acc[I][(J) + 1] = Elem<F16>::mfma(wfr[S1][KK][I], xfr[S1][KK][(J) + 1], acc[I][(J) + 1]); \
+        WRES_SB
 #define WRES_STEP(TAP, SET)                                                                    \
     {                                                                                          \
-        WRES_READ(TAP, SET)                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        WRES_MFMA((SET) ^ 1)                                                                   \
+        WRES_RW(SET, 0, 0, TAP) WRES_RW(SET, 0, 1, TAP) WRES_M2((SET) ^ 1, 0, 0, 0)             \
+        WRES_RW(SET, 0, 2, TAP) WRES_RW(SET, 0, 3, TAP) WRES_M2((SET) ^ 1, 0, 0, 2)             \
+        WRES_RX(SET, 0, 0, TAP) WRES_RX(SET, 0, 1, TAP) WRES_M2((SET) ^ 1, 0, 1, 0)             \
+        WRES_RX(SET, 0, 2, TAP) WRES_RX(SET, 0, 3, TAP) WRES_M2((SET) ^ 1, 0, 1, 2)             \
+        WRES_RW(SET, 1, 0, TAP) WRES_RW(SET, 1, 1, TAP) WRES_M2((SET) ^ 1, 0, 2, 0)             \
+        WRES_RW(SET, 1, 2, TAP) WRES_RW(SET, 1, 3, TAP) WRES_M2((SET) ^ 1, 0, 2, 2)             \
+        WRES_RX(SET, 1, 0, TAP) WRES_RX(SET, 1, 1, TAP) WRES_M2((SET) ^ 1, 0, 3, 0)             \
+        WRES_RX(SET, 1, 2, TAP) WRES_RX(SET, 1, 3, TAP) WRES_M2((SET) ^ 1, 0, 3, 2)             \
+        WRES_M2((SET) ^ 1, 1, 0, 0) WRES_M2((SET) ^ 1, 1, 0, 2) WRES_M2((SET) ^ 1, 1, 1, 0) WRES_M2((SET) ^ 1, 1, 1, 2) \
+        WRES_M2((SET) ^ 1, 1, 2, 0) WRES_M2((SET) ^ 1, 1, 2, 2) WRES_M2((SET) ^ 1, 1, 3, 0) WRES_M2((SET) ^ 1, 1, 3, 2) \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
+        WRES_SB                                                                                \
     }
         WRES_READ(0, 0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,6 +228,10 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         WRES_STEP(5, 1) WRES_STEP(6, 0) WRES_STEP(7, 1) WRES_STEP(8, 0)
         WRES_MFMA(0)
 #undef WRES_STEP
+#undef WRES_M2
+#undef WRES_RX
+#undef WRES_RW
+#undef WRES_SB
 #undef WRES_MFMA
 #undef WRES_READ
 

@@ -1,5 +1,5 @@
 // SingleInputRegressor(18, 18, 3) for gfx950: ResNet-18 encoder (PR/models/resnet.py:124-216) as a plan of
-// MFMA implicit-GEMM convolutions (conv.hip) over zero-bordered NHWC bf16 feature maps, + the IEF MLP
+// MFMA convolutions (conv_stem / conv_wres / conv_patch / conv_ring .hip) over zero-bordered NHWC 16-bit feature maps, + the IEF MLP
 // (PR/models/ief_module.py:48-64) in fp32.  Eval-mode BatchNorm is folded into weights/bias at load.
 #include <cmath>
 #include <cstdlib>
@@ -56,35 +56,6 @@ __global__ void proxy_pack_kernel(const float* __restrict__ src, uint16_t* __res
         if (inside) { v0 = s[(size_t)c * kWH * kWH]; v1 = s[(size_t)(c + 1) * kWH * kWH]; }
         d[c / 2] = Elem<F16>::pack2(v0, v1);
     }
-}
-
-// 3x3/2 max-pool, pad 1 (resnet.py:149) on a post-ReLU map: the zero border equals -inf padding.
-// in [B][2*Ho+2][2*Wo+2][C] -> out [B][Ho+2][Wo+2][C] interior; one thread per (pixel, 8 channels).
-__global__ void maxpool_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Ho, int Wo, int C) {
-    const int groups = C / 8;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)B * Ho * Wo * groups;
-    if (idx >= total) return;
-    const int g = idx % groups;
-    size_t t = idx / groups;
-    const int wo = t % Wo; t /= Wo;
-    const int ho = t % Ho;
-    const int b = (int)(t / Ho);
-    const int Wi = 2 * Wo + 2, Hi = 2 * Ho + 2;
-    // post-ReLU values are >= +0, and for non-negative bf16 / fp16 alike the numeric order is the order of the
-    // 16-bit patterns: an integer max per half-word, no conversion, the same code for both element types
-    uint32_t o[4] = {0u, 0u, 0u, 0u};
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-            const uint4 v = *reinterpret_cast<const uint4*>(in + (((size_t)b * Hi + 2 * ho + r) * Wi + 2 * wo + c) * C + g * 8);
-            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t lo = max(o[i] & 0xFFFFu, u[i] & 0xFFFFu), hi = max(o[i] >> 16, u[i] >> 16);
-                o[i] = lo | (hi << 16);
-            }
-        }
-    *reinterpret_cast<uint4*>(out + (((size_t)b * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * C + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // padded NHWC bf16 -> NCHW fp32 (parity tap)
@@ -199,7 +170,6 @@ struct spsp_regressor {
     float* init_params;
     // feature maps (bf16, zero border)
     uint16_t* x0;          // [B][262][262][18]
-    uint16_t* c1;          // [B][130][130][64]
     uint16_t* p1;          // [B][66][66][64] max-pool output
     uint16_t* l[4][3];     // layer L: [B][S+2][S+2][C], S = 64,32,16,8; C = 64,128,256,512
     float *feats, *params, *h1, *h2;
@@ -207,15 +177,8 @@ struct spsp_regressor {
     int last_B;
     unsigned int* counters;  // tile-scheduler words of the persistent kernels (zeroed at the start of every forward)
     int next_counter;
-    float* slab;           // split-K fp32 slabs
-    size_t slab_floats;
-    // per residual stage: ring tile (kRingNone = first-generation kernel) and split-K factor
-    RingTile ring[4];
-    int splitk[4];
-    bool use_patch;        // 3x3 stride-1 convs through conv_patch.hip
-    bool use_wres;         // layer1 through conv_wres.hip
-    int patch_splitk[4];   // split-K factor of the patch kernel per stage (deep stages have fewer tiles than CUs at 32 crops)
-    int patch_variant[4];  // 0: 4-wave workgroups, 1: 8-wave workgroups (K-step split over wave pairs), 3: 1 + grouped ring, 4: 3 + two patch buffers
+    RingTile ring[4];      // per residual stage: tile of the ring kernel (stride-2 / 1x1 convs; every conv of a ragged batch)
+    bool patch_db[4];      // per residual stage: two patch buffers in the patch kernel
 };
 
 namespace {
@@ -224,8 +187,9 @@ const int kLayerS[4] = {64, 32, 16, 8};
 const int kLayerC[4] = {64, 128, 256, 512};
 
 // conv `ci` reading map `in` (spatial Si, channels Ci, border bi) writing map `out` (spatial So, border 1)
+// (ci2 >= 0: the 1x1 stride-2 downsample conv `ci2` of the stage rides in the same launch, writing out2)
 int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int Si, int bi, uint16_t* out, const uint16_t* res, int relu,
-             int B, ConvTile tile, float* pool_out, hipStream_t st, int L = -1) {
+             int B, float* pool_out, hipStream_t st, int L, int ci2 = -1, uint16_t* out2 = nullptr) {
     const ConvDesc& d = kConvs[ci];
     ConvArgs a;
     std::memset(&a, 0, sizeof a);
@@ -233,7 +197,6 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     a.f16 = r->f16;
     const int Wi = Si + 2 * bi;
     a.in_pix = d.cin; a.in_row = Wi * d.cin; a.in_img = Wi * Wi * d.cin;
-    if (ci == 0) { a.in_row = kWWp * d.cin; a.in_img = kWHp * kWWp * d.cin; }     // native input: 262 rows x 264 columns
     const int conv_pad = d.k / 2;
     a.in_off = (bi - conv_pad) * (a.in_row + a.in_pix);
     const int So = Si / d.stride;
@@ -241,47 +204,27 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     a.out_off = a.out_row + a.out_pix;
     a.Ho = So; a.Wo = So; a.M = B * So * So; a.N = d.cout;
     a.stride = d.stride;
-    if (ci == 0) { a.kw_steps = 1; a.chunks = 1; a.nsteps = 7; }
-    else { a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks; }
+    a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks;
     a.relu = relu;
     a.splitk = 1;
     a.counter = r->counters + (r->next_counter < 15 ? r->next_counter : 15);
-    if (L >= 0 && r->use_wres && conv_wres_supported(a)) {
+    if (conv_wres_supported(a)) {                      // layer1: 3x3 / 1, 64 -> 64, weights resident in LDS
         ++r->next_counter;
         ProfScope ps(ctx, kKConvWres, st);
         return launch_conv_wres(a, ctx->num_cus, st);
     }
-    if (L >= 0 && r->use_patch && conv_patch_supported(a)) {
-        const int v = r->patch_variant[L];
-        const int kid3 = a.Wo == 8 ? (v >= 3 ? kKPatchW8Grp : v ? kKPatchW8Big : kKPatchW8Small)
-                                   : (v >= 3 ? kKPatchW16Grp : v ? kKPatchW16Big : kKPatchW16Small);
-        int sk = r->patch_splitk[L];
-        while (sk > 1 && (a.chunks % sk != 0 || (size_t)sk * a.M * a.N > r->slab_floats)) sk >>= 1;
-        if (sk > 1) { a.splitk = sk; a.part = r->slab; }
-        ProfScope ps(ctx, kid3, st);
-        const int rc = launch_conv_patch(a, v, st);
-        if (rc != SPSP_OK || sk <= 1) return rc;
-        return launch_splitk_epilogue(a, st);
+    if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
+        ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st);
+        return launch_conv_patch(a, r->patch_db[L], st);
     }
-    if (L >= 0 && r->ring[L] != kRingNone) {
-        const RingTile rt = r->ring[L];
-        const int bm = (rt == kRing64x128s3 || rt == kRing64x64s4) ? 64 : 128;
-        const int bn = (rt == kRing128x64s3 || rt == kRing128x64s4 || rt == kRing64x64s4) ? 64 : 128;
-        if (a.M % bm == 0 && a.N % bn == 0) {
-            int sk = r->splitk[L];
-            while (sk > 1 && (a.nsteps / sk < 4 || (size_t)sk * a.M * a.N > r->slab_floats)) sk >>= 1;
-            a.splitk = sk;
-            a.part = r->slab;
-            ProfScope ps(ctx, kKConvRing, st);
-            return launch_conv_ring(a, rt, st);
-        }
-    }
-    if (ci == 0) {
-        ProfScope ps(ctx, kKConv1Half, st);
-        return launch_conv1_patch(a, st);
-    }
-    set_error("regressor: no kernel for conv %s at batch %d", d.name, B);
-    return SPSP_EINVAL;
+    // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
+    if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
+    const RingTile rt = r->ring[L];
+    const int bm = (rt == kRing64x128s3 || rt == kRing64x64s4) ? 64 : 128;
+    const int bn = (rt == kRing128x64s3 || rt == kRing128x64s4 || rt == kRing64x64s4) ? 64 : 128;
+    SPSP_REQUIRE(a.M % bm == 0 && a.N % bn == 0, "regressor: conv %s at batch %d does not tile (%d x %d)", d.name, B, bm, bn);
+    ProfScope ps(ctx, kKConvRing, st);
+    return launch_conv_ring(a, rt, st);
 }
 
 }  // namespace
@@ -340,35 +283,18 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     TRY(r->pool.upload(&r->init_params, w->init_params, (size_t)kNPar));
     const size_t B = max_batch;
     TRY(r->pool.alloc(&r->x0, B * kNativeElems, true));
-    TRY(r->pool.alloc(&r->c1, B * 130 * 130 * 64, true));
     TRY(r->pool.alloc(&r->p1, B * 66 * 66 * 64, true));
     for (int L = 0; L < 4; ++L)
         for (int j = 0; j < 3; ++j)
             TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
-    r->slab_floats = B * 65536 * 4;
-    TRY(r->pool.alloc(&r->slab, r->slab_floats));
     TRY(r->pool.alloc(&r->counters, 16, true));
-    {   // conv plan for the residual stages
-        const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};   // measured best at 32 crops
-        const int def_s[4] = {1, 1, 1, 1};
-        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->splitk[L] = def_s[L]; }
-        r->use_patch = true;
-        r->use_wres = true;
-        // measured at 32 crops: 8 waves + grouped ring (one barrier per kernel row) on every stage; two patch buffers
-        // where the layer has fewer tiles than the chip has CUs (layer3, layer4).  Layer2 fills every CU exactly once
-        // and keeps ONE patch buffer (89 KB), so that a fit workgroup (38 KB) already resident on a CU does not push
-        // its tile into a second round.  A/B of 3 runs each: 3333 87.4 k, 4444 88.4 k, 3344 88.6 k, 3334 88.7 k players/s.
-        const int def_v[4] = {3, 3, 4, 4};
-        for (int L = 0; L < 4; ++L) r->patch_variant[L] = def_v[L];
-        for (int L = 0; L < 4; ++L) r->patch_splitk[L] = 1;
-#ifdef SPSP_TUNING   // tuning builds only (make TUNING=1): plan overrides from the environment; the product has ONE plan
-        if (const char* pe = getenv("SPSP_CONV_PATCH")) r->use_patch = atoi(pe) != 0;
-        if (const char* pe = getenv("SPSP_CONV_WRES")) r->use_wres = atoi(pe) != 0;
-        if (const char* ps = getenv("SPSP_PATCH_SPLITK"))      // e.g. "1124"
-            for (int L = 0; L < 4 && ps[L]; ++L) r->patch_splitk[L] = ps[L] - '0';
-        if (const char* pv = getenv("SPSP_PATCH_VARIANT"))       // e.g. "0111"
-            for (int L = 0; L < 4 && pv[L]; ++L) r->patch_variant[L] = pv[L] - '0';
-#endif
+    {   // plan of the residual stages (ONE plan; measured at 32 crops)
+        const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};
+        // two patch buffers where the layer has fewer tiles than the chip has CUs (layer3, layer4); layer2 fills every
+        // CU exactly once and keeps ONE (89 KB), so that a fit workgroup (38 KB) already resident on a CU does not push
+        // its tile into a second round
+        const bool def_db[4] = {false, false, true, true};
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; }
     }
     TRY(r->pool.alloc(&r->feats, B * kFeat));
     TRY(r->pool.alloc(&r->params, B * kNPar));
@@ -414,15 +340,12 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
     // tile-scheduler counters of this forward's persistent launches
     SPSP_HIP_CHECK(hipMemsetAsync(r->counters, 0, 16 * sizeof(unsigned int), st));
     r->next_counter = 0;
-    // stem
-    TRY(run_conv(ctx, r, 0, x0, kWH, kPad, r->c1, nullptr, 1, B, kTileConv1, nullptr, st));
+    // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
     {
-        const size_t total = (size_t)B * 64 * 64 * 8;
-        ProfScope ps(ctx, kKMaxpool, st);
-        maxpool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(r->c1, r->p1, B, 64, 64, 64);
-        SPSP_HIP_CHECK(hipGetLastError());
+        ProfScope ps(ctx, kKStem, st);
+        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, st));
     }
-    r->stage_ptr[0] = r->c1;
+    r->stage_ptr[0] = nullptr;
     r->stage_ptr[1] = r->p1;
     // residual stages
     const uint16_t* x = r->p1;
@@ -430,24 +353,23 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
     int ci = 1;
     for (int L = 0; L < 4; ++L) {
         const int S = kLayerS[L];
-        ConvTile tile = L == 0 ? kTile128x64 : L == 1 ? (B * 8 >= 256 ? kTile128x128 : kTile64x128) : L == 2 ? kTile64x128 : kTile64x64;
         uint16_t *ba = r->l[L][0], *bb = r->l[L][1], *bc = r->l[L][2];
         if (L == 0) {
-            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st, L));         // t   = relu(bn1(conv1(x)))
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, x, 1, B, tile, nullptr, st, L));           // out = relu(bn2(conv2(t)) + x)
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, nullptr, st, L));         // t   = relu(bn1(conv1(x)))
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, x, 1, B, nullptr, st, L));           // out = relu(bn2(conv2(t)) + x)
             ci += 2;
-            TRY(run_conv(ctx, r, ci, bb, S, 1, ba, nullptr, 1, B, tile, nullptr, st, L));
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st, L));
+            TRY(run_conv(ctx, r, ci, bb, S, 1, ba, nullptr, 1, B, nullptr, st, L));
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, nullptr, st, L));
             ci += 2;
             x = bc;
         } else {
-            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, tile, nullptr, st, L));         // t   (stride 2)
-            TRY(run_conv(ctx, r, ci + 2, x, xs, 1, bb, nullptr, 0, B, tile, nullptr, st, L));     // identity = downsample(x)
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, tile, nullptr, st, L));          // out -> bc
+            // t = relu(bn1(conv1(x))) (3x3 stride 2) and identity = downsample(x) (1x1 stride 2, same input pixels) in ONE launch
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, nullptr, st, L, ci + 2, bb));
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, nullptr, st, L));          // out -> bc
             ci += 3;
-            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, tile, nullptr, st, L));         // t
+            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, nullptr, st, L));         // t
             float* pool = (L == 3) ? r->feats : nullptr;
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, tile, pool, st, L));             // out -> bb (+ avg-pool)
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, pool, st, L));             // out -> bb (+ avg-pool)
             ci += 2;
             x = bb;
         }
@@ -484,6 +406,7 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
 int spsp_regressor_read_stage(spsp_ctx* ctx, spsp_regressor* r, int stage, int B, float* out_nchw, void* stream) {
     SPSP_REQUIRE(ctx && r && out_nchw, "spsp_regressor_read_stage: NULL argument");
     SPSP_REQUIRE(stage >= 0 && stage < 6, "spsp_regressor_read_stage: stage %d out of range", stage);
+    SPSP_REQUIRE(stage != 0, "spsp_regressor_read_stage: stage 0 (conv1 + ReLU) is never materialised -- the stem kernel pools in registers; read stage 1");
     SPSP_REQUIRE(B > 0 && B <= r->last_B, "spsp_regressor_read_stage: B=%d but the last forward ran %d crops", B, r->last_B);
     const int S = stage == 0 ? 128 : kLayerS[stage < 2 ? 0 : stage - 2];
     const int C = stage < 2 ? 64 : kLayerC[stage - 2];
