@@ -228,6 +228,30 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant /* 0 = A camera, 1 
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream);
 
+/* ---- multi-view joint fit: replaces the optimisation body of multi_view_optimization (PR/player_recon.py:1691-1979):
+ *      V <= 4 views of one player share body pose and betas, each view has its camera and global orientation.
+ *      `rounds` x { block 1: Adam over the stacked per-view cameras + orientations; block 2: Adam over the shared
+ *      parameters }, `iters` epochs per block, an epoch = one train step per view + a validation pass; the iterate with
+ *      the lowest mean joints2D_l2es is kept (per block and as the global record that is returned).  optimise_body_pose
+ *      = 0 reproduces the reference exactly (its block 2 reaches betas only: the posed tensor is concatenated before
+ *      requires_grad is set, :1724-1731); 1 also optimises body_pose idx {0-5, 8-20} as the loop intends.  Views are
+ *      visited in order 0..V-1 (the reference shuffles); the silhouette gate of the record is row 8f-4. */
+typedef struct {
+    int    iters;               /* 50 epochs per block (S/global_var.py:79) */
+    int    rounds;              /* 3 (PR/player_recon.py:1720) */
+    double lr;                  /* 1e-3 (S/global_var.py:71) */
+    double beta1, beta2, eps;   /* torch.optim.Adam defaults */
+    double loss_weight;         /* 1.0 */
+    float  img_wh, loss_wh;     /* 512, 256 */
+    int    optimise_body_pose;  /* 0 = as the reference behaves, 1 = as it intends */
+} spsp_fit_multiview_config;
+void spsp_fit_multiview_config_default(spsp_fit_multiview_config* c);
+/* In place: body_pose [B,23,9] (in: the mean of the views' single-view results, :1691-1694), betas [B,10] (in: mean),
+ * cam [B,V,3], global_orient [B,V,9] (in: per view), joints2d [B,V,17,2] pixels; out: the best record.
+ * val_hist: optional [B, rounds*2*iters] mean joints2D_l2es of every epoch's validation pass. */
+int spsp_fit_multiview(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose,
+                       float* betas, float* cam, float* global_orient, const float* joints2d, float* val_hist, void* stream);
+
 /* ---- exchange step without torch: ONE RCCL all-gather of the packed records over xGMI, for hosts that
  *      drive this library directly.  Rank 0 calls spsp_comm_unique_id and ships the 128 bytes to the other ranks
  *      (any channel); every rank calls spsp_comm_init_rank on its own device; spsp_allgather_records gathers

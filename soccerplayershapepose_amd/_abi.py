@@ -61,6 +61,12 @@ class FitConfig(C.Structure):
                 ('img_wh', C.c_float), ('loss_wh', C.c_float), ('select_mode', C.c_int)]
 
 
+class FitMultiviewConfig(C.Structure):
+    _fields_ = [('iters', C.c_int), ('rounds', C.c_int), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+                ('eps', C.c_double), ('loss_weight', C.c_double), ('img_wh', C.c_float), ('loss_wh', C.c_float),
+                ('optimise_body_pose', C.c_int)]
+
+
 class PipelineOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('cam', 'pose6d', 'betas', 'rotmats', 'vertices', 'joints', 'translation',
                                           'record', 'relate_tmp')]
@@ -141,6 +147,8 @@ _PROTOS = {
     'spsp_smpl_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     'spsp_fit_config_default': (None, [C.POINTER(FitConfig), C.c_int]),
     'spsp_fit': (C.c_int, [_vp, _vp, C.POINTER(FitConfig), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    'spsp_fit_multiview_config_default': (None, [C.POINTER(FitMultiviewConfig)]),
+    'spsp_fit_multiview': (C.c_int, [_vp, _vp, C.POINTER(FitMultiviewConfig), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

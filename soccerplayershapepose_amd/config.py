@@ -21,6 +21,7 @@ SMPL_TO_KPRCNN_MAP = [24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7,
 # ------------------------ Fit defaults (S/global_var.py:71,75,110; PR/PyTorch3DTest.py:3077-3080) ----
 player_recon_train_regressor_learning_rate = 1e-3
 player_recon_single_view_iteration = 100
+player_recon_multi_view_iteration = 50       # S/global_var.py:79
 texture_single_opt_interation = 50
 optimize_camera_learning_rate = 0.01
 optimize_camera_iterations = 50

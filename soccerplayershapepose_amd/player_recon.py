@@ -91,6 +91,57 @@ def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp,
     return SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam)
 
 
+def multi_view_optimization(smpl, body_pose, global_orient, betas, translation, joints2D, interation=None, lr=None,
+                            rounds=3, optimise_body_pose=False, return_history=False):
+    """Optimisation body of `multi_view_optimization` (`PR/player_recon.py:1691-1979`) for a batch of players seen in
+    V <= 4 views each.  Inputs are the per-view single-view results the reference loads from its npz records
+    (`:1673-1689`; `records.load_record`): body_pose [B,V,23,3,3], global_orient [B,V,1,3,3], betas [B,V,10],
+    translation [B,V,3], and the detected joints2D [B,V,17,>=2] (512-px space).
+
+    As in the reference the shared body pose and betas start from the MEAN over the views (`:1691-1694`), every view
+    keeps its own camera (recovered from its translation, `:1689`) and orientation, and `rounds` x {camera block, pose
+    block} of `interation` epochs run with the best mean joints2D_l2es iterate kept (csrc/fit_mv_core.hpp).
+    optimise_body_pose=False reproduces the reference, whose pose block only ever moves betas (the posed tensor is
+    concatenated before requires_grad is set, `:1724-1731`); True optimises body_pose idx {0-5, 8-20} as intended.
+
+    Returns what the reference saves (`:1976-1979`): body_pose [B,23,3,3], betas [B,10] (-> data.npz) and per view
+    translation [B,V,3], global_orient [B,V,1,3,3] (-> <view>.npz), plus cam_wp [B,V,3]."""
+    from .utils.cam_utils import convert_camera_translation_to_weak_perspective_torch
+    bp = rt.dev_f32(body_pose)
+    r = rt.get(bp.device)
+    if bp.dim() != 5 or tuple(bp.shape[2:]) != (23, 3, 3):
+        raise ValueError(f'multi_view_optimization: body_pose must be [B,V,23,3,3], got {tuple(bp.shape)}')
+    B, V = bp.shape[:2]
+    if not 1 <= V <= 4:
+        raise ValueError(f'multi_view_optimization: {V} views (the kernel holds 1..4)')
+    go = rt.dev_f32(global_orient, r.device).reshape(B, V, 9).contiguous().clone()
+    be = rt.dev_f32(betas, r.device).reshape(B, V, 10)
+    tr = rt.dev_f32(translation, r.device).reshape(B, V, 3)
+    j2d = rt.dev_f32(torch.as_tensor(joints2D)[..., :2], r.device).reshape(B, V, 17, 2).contiguous()
+    cam = convert_camera_translation_to_weak_perspective_torch(tr.reshape(B * V, 3), config.FOCAL_LENGTH,
+                                                               config.proxy_rep_input_wh).reshape(B, V, 3).contiguous()
+    body = bp.mean(dim=1).reshape(B, 207).contiguous()           # body_pose_mean, betas_mean (:1691-1694)
+    bmean = be.mean(dim=1).contiguous()
+    cfg = _abi.FitMultiviewConfig()
+    r.lib.spsp_fit_multiview_config_default(C.byref(cfg))
+    cfg.iters = int(interation if interation is not None else config.player_recon_multi_view_iteration)
+    cfg.rounds = int(rounds)
+    if lr is not None:
+        cfg.lr = float(lr)
+    cfg.optimise_body_pose = 1 if optimise_body_pose else 0
+    hist = torch.empty((B, cfg.rounds * 2 * cfg.iters), dtype=torch.float32, device=r.device) if return_history else None
+    smpl.to(r.device)
+    r.check(r.lib.spsp_fit_multiview(r.ctx, smpl.handle, C.byref(cfg), B, V, rt.ptr(body), rt.ptr(bmean), rt.ptr(cam),
+                                     rt.ptr(go), rt.ptr(j2d), rt.ptr(hist), r.stream()), 'spsp_fit_multiview')
+    trans = convert_weak_perspective_to_camera_translation_torch(cam.reshape(B * V, 3), config.FOCAL_LENGTH,
+                                                                 config.proxy_rep_input_wh).reshape(B, V, 3)
+    out = SimpleNamespace(body_pose=body.reshape(B, 23, 3, 3), betas=bmean, translation=trans,
+                          global_orient=go.reshape(B, V, 1, 3, 3), cam_wp=cam)
+    if return_history:
+        out.val_l2e_history = hist.reshape(B, cfg.rounds, 2, cfg.iters)
+    return out
+
+
 def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape', iters=50, lr=None,
                         select_mode=_abi.FIT_SELECT_LAST, return_vertices2d=False, pose_relation=None, boxes=None,
                         return_record=False):

@@ -1,0 +1,101 @@
+// HOST EMULATION of the multi-view fit kernel -- test infrastructure only (never loaded by the product).
+// Same phases as the gfx950 kernel (csrc/fit_core.hpp + csrc/fit_mv_core.hpp), same driver sequence as
+// csrc/fit_mv.hip with `for lane in 0..255` per phase in place of the workgroup and its barriers, so the CPU suite
+// checks the kernel's bookkeeping (stacked-tensor Adam, per-block best, global record) against the autograd oracle.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../soccerplayershapepose_amd/csrc/fit_mv_core.hpp"
+#include "../../soccerplayershapepose_amd/csrc/smpl_host.hpp"
+
+using namespace spsp;
+
+#define ALL_LANES(stmt) for (int lane = 0; lane < kFitLanes; ++lane) { stmt; }
+
+extern "C" int fit_mv_emulate(const spsp_smpl_arrays* model, int iters, int rounds, double lr, double beta1, double beta2,
+                              double eps, double loss_weight, float img_wh, float loss_wh, int optimise_body_pose, int B, int V,
+                              float* body, float* betas, float* cam, float* G, const float* joints2d, float* val_hist) {
+    SmplHostImage h;
+    if (!smpl_prepare(*model, h, false).empty()) return -1;
+    if (V < 1 || V > kMaxViews) return -2;
+    const float* fitc = h.fitc.data();
+    FitParams P;
+    P.iters = iters; P.lr = lr; P.beta1 = beta1; P.beta2 = beta2; P.eps = eps;
+    P.param_mask = 0; P.img_wh = img_wh; P.loss_wh = loss_wh;
+    P.log_var = (float)(-std::log(loss_weight + 1e-6));
+    P.weight = std::exp(-P.log_var);
+    P.select_mode = SPSP_FIT_SELECT_LAST; P.num_levels = h.num_levels;
+    const int L = h.num_levels;
+    const uint32_t mask_shared = SPSP_FIT_BETAS | (optimise_body_pose ? 0x003FFE7Eu : 0u);
+    const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2), epsf = (float)eps;
+    std::vector<FitShared> sv(1);
+    std::vector<MvShared> mvv(1);
+    FitShared& s = sv[0];
+    MvShared& m = mvv[0];
+    for (int b = 0; b < B; ++b) {
+        std::vector<FitLane> rv(kFitLanes);
+        FitLane* r = rv.data();
+        float Rinit[216];
+        for (int i = 0; i < 216; ++i) Rinit[i] = i < 9 ? G[((size_t)b * V) * 9 + i] : body[(size_t)b * 207 + (i - 9)];
+        for (int i = 0; i < V * kViewPrm; ++i) {
+            const int u = i / kViewPrm, p = i - u * kViewPrm;
+            m.vprm[i] = p < 3 ? cam[((size_t)b * V + u) * 3 + p] : G[((size_t)b * V + u) * 9 + (p - 3)];
+        }
+        for (int i = 0; i < V * 34; ++i) m.vtgt[i] = joints2d[(size_t)b * V * 34 + i];
+        m.best_val = INFINITY; m.val_acc = 0.f; m.improved = 0;
+        ALL_LANES(fit_init(s, r[lane], lane, fitc, h.parents, h.level_joints.data(), h.level_start, h.child_start, h.child_list,
+                           Rinit, betas + (size_t)b * 10, cam + (size_t)b * V * 3, joints2d + (size_t)b * V * 34, 0u));
+        for (int i = 0; i < V * kViewPrm; ++i) m.best_views[i] = m.vprm[i];
+        for (int i = 0; i < 232; ++i) m.best_shared[i] = s.prm[i];
+        float* vh = val_hist ? val_hist + (size_t)b * rounds * 2 * iters : nullptr;
+        auto forward = [&]() {
+            ALL_LANES(fit_p1(s, r[lane], lane));
+            ALL_LANES(fit_p2(s, lane));
+            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], l)); }
+            ALL_LANES(fit_p4(s, r[lane], lane));
+            ALL_LANES(fit_p5(s, lane));
+            ALL_LANES(fit_p6(s, r[lane], lane, P));
+            ALL_LANES(fit_p7(s, r[lane], lane));
+        };
+        auto backward = [&]() {
+            ALL_LANES(fit_p8(s, lane, P, 0, nullptr, nullptr));
+            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], l)); }
+            ALL_LANES(fit_p10(s, r[lane], lane));
+            ALL_LANES(fit_p11(s, r[lane], lane));
+        };
+        for (int round = 0; round < rounds; ++round)
+            for (int block = 0; block < 2; ++block) {
+                ALL_LANES(mv_block_start(s, m, r[lane], lane, block, V, mask_shared));
+                double b1t = 1.0, b2t = 1.0;
+                for (int ep = 0; ep < iters; ++ep) {
+                    for (int v = 0; v < V; ++v) {
+                        b1t *= beta1; b2t *= beta2;
+                        const float step_size = (float)(lr / (1.0 - b1t));
+                        const float bc2_sqrt = (float)std::sqrt(1.0 - b2t);
+                        ALL_LANES(mv_load_view(s, m, lane, v));
+                        forward();
+                        backward();
+                        if (block == 0) { ALL_LANES(mv_adam_views(s, m, r[lane], lane, v, V, w1, b2f, w2, epsf, step_size, bc2_sqrt)); }
+                        else { ALL_LANES(fit_p12(s, r[lane], lane, w1, b2f, w2, epsf, step_size, bc2_sqrt)); }
+                    }
+                    for (int v = 0; v < V; ++v) {
+                        ALL_LANES(mv_load_view(s, m, lane, v));
+                        forward();
+                        ALL_LANES(mv_val_add(s, m, lane, v == 0));
+                    }
+                    ALL_LANES(mv_epoch_decide(m, lane, V, vh, (round * 2 + block) * iters + ep));
+                    ALL_LANES(mv_epoch_snapshot(s, m, lane, block, V));
+                }
+                ALL_LANES(mv_block_end(s, m, lane, block, V));
+            }
+        for (int i = 0; i < 207; ++i) body[(size_t)b * 207 + i] = m.best_shared[kPrmR + 9 + i];
+        for (int i = 0; i < 10; ++i) betas[(size_t)b * 10 + i] = m.best_shared[kPrmBeta + i];
+        for (int i = 0; i < V * kViewPrm; ++i) {
+            const int u = i / kViewPrm, p = i - u * kViewPrm;
+            if (p < 3) cam[((size_t)b * V + u) * 3 + p] = m.best_views[i];
+            else G[((size_t)b * V + u) * 9 + (p - 3)] = m.best_views[i];
+        }
+    }
+    return 0;
+}

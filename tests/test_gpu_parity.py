@@ -2,6 +2,8 @@
 oracle on identical seeded inputs, and against the committed golden vectors.  Tolerances are stated per test:
 fp32 kernels (SMPL, fit, geometry) are held to ~1e-5; the bf16 MFMA backbone is checked tightly against the
 oracle's bf16-emulation mode and loosely against the fp32 reference outputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -239,6 +241,80 @@ def test_fit_is_deterministic_and_batch_independent(smpl_gpu, dev):
     Rg, bg, cg = (torch.from_numpy(a[5:6]).to(dev).contiguous() for a in (R, b, cam))
     fit_players(smpl_gpu, Rg, bg, cg, tgt[5:6], variant=1, iters=50)
     assert torch.equal(Rg[0], runs[0][0][5]) and torch.equal(cg[0], runs[0][2][5])
+
+
+# ---------------------------------------------------------------- multi-view fit (8f-3) and the on-disk records (a14)
+@pytest.mark.parametrize('optimise_body_pose', [False, True])
+def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev, optimise_body_pose, tmp_path):
+    """`multi_view_optimization` on the GPU (one workgroup per player, all rounds / blocks / epochs in one launch)
+    against the autograd restatement of `PR/player_recon.py:1691-1979`, two players with 3 and ... views handled as
+    separate calls (V is per call), the whole path starting from and ending in the reference's npz records."""
+    from soccerplayershapepose_amd import records
+    from soccerplayershapepose_amd.player_recon import multi_view_optimization
+    from oracle import fit_multiview as OMV
+    from test_fit_multiview_emulation import multiview_case
+    iters, rounds = 6, 2
+    for V, seed in ((3, 31), (2, 7), (4, 19)):
+        cases = [multiview_case(smpl_model_np, V, seed=seed + 100 * b) for b in range(2)]      # B = 2 players
+        # the single-view results live in npz records (a14): write them, load them, start the multi-view fit from them
+        recs = []
+        for b, views in enumerate(cases):
+            row = []
+            for v, (body, go, betas, trans, _) in enumerate(views):
+                path = str(tmp_path / f'p{b}_V{V}_view{v}.npz')
+                records.save_record(path, body, go, betas, trans)
+                row.append(records.load_record(path))
+            recs.append(row)
+        stack = lambda k: np.stack([np.stack([r[k][0] for r in row]) for row in recs])
+        j2d = np.stack([np.stack([v[4] for v in views]) for views in cases])
+        out = multi_view_optimization(smpl_gpu, stack('body_pose'), stack('global_orient'), stack('betas'), stack('translation'), j2d,
+                                      interation=iters, rounds=rounds, optimise_body_pose=optimise_body_pose, return_history=True)
+        assert out.body_pose.shape == (2, 23, 3, 3) and out.translation.shape == (2, V, 3) and out.global_orient.shape == (2, V, 1, 3, 3)
+        for b, views in enumerate(cases):
+            t = lambda k: torch.from_numpy(np.stack([v[k] for v in views]))
+            ref = OMV.fit_multi_view(oracle_smpl, t(0), t(1), t(2), t(3), [v[4] for v in views], iters=iters, rounds=rounds,
+                                     stale_pose_cat=not optimise_body_pose)
+            np.testing.assert_allclose(out.val_l2e_history[b].cpu().numpy().reshape(-1), ref['val_history'], rtol=2e-4, atol=2e-3)
+            np.testing.assert_allclose(out.cam_wp[b].cpu().numpy(), ref['cam_wp'][:, 0], atol=5e-5)
+            np.testing.assert_allclose(out.global_orient[b, :, 0].cpu().numpy(), ref['global_orient'][:, 0, 0], atol=5e-5)
+            np.testing.assert_allclose(out.betas[b].cpu().numpy(), ref['betas'][0], atol=5e-5)
+            np.testing.assert_allclose(out.body_pose[b].cpu().numpy(), ref['body_pose'][0], atol=5e-5)
+            np.testing.assert_allclose(out.translation[b].cpu().numpy(), ref['translation'][:, 0], rtol=2e-5)
+            # ... and back to disk in the multi-view layout (:1976-1979)
+            d = str(tmp_path / f'out_p{b}_V{V}_{int(optimise_body_pose)}')
+            records.save_multiview_record(d, out.body_pose[b:b + 1], out.betas[b:b + 1],
+                                          {f'view{v}.png': (out.translation[b, v:v + 1], out.global_orient[b, v]) for v in range(V)})
+            bp, be, vs = records.load_multiview_record(d)
+            assert np.array_equal(bp[0], out.body_pose[b].cpu().numpy()) and len(vs) == V
+    with pytest.raises(ValueError):
+        multi_view_optimization(smpl_gpu, np.zeros((1, 5, 23, 3, 3), np.float32), np.zeros((1, 5, 1, 3, 3), np.float32),
+                                np.zeros((1, 5, 10), np.float32), np.ones((1, 5, 3), np.float32), np.zeros((1, 5, 17, 2), np.float32))
+
+
+def test_single_view_fit_warm_started_from_its_own_record_continues_the_trajectory(smpl_gpu, smpl_model_np, dev, tmp_path):
+    """a14 as a warm start (`PR/player_recon.py:1673-1689`): fit 20 iterations, save the reference-layout record, load it,
+    and fit 1 more iteration from it == what a fresh optimiser does from the same parameters held in memory (the record
+    stores translation, so the camera goes through translation -> cam_wp: equal to fp32 rounding of that round trip)."""
+    from soccerplayershapepose_amd import records
+    from soccerplayershapepose_amd.player_recon import single_view_optimization
+    from oracle import smpl as OS
+    B = 3
+    R, betas, cam = S.pose_params(B, seed=41, body_deg=20, global_deg=30)
+    _, j = OS.smpl_forward_np(smpl_model_np, R, betas)
+    tgt = S.fit_targets_from_joints(j, cam * np.array([1.1, 1, 1], np.float32), seed=42)
+    Rn, bn, _ = S.pose_params(B, seed=43, body_deg=8, global_deg=10)
+    R0 = (Rn.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    fit = single_view_optimization(smpl_gpu, R0[:, 1:], R0[:, :1], betas + bn / 3, cam, tgt, interation=20)
+    paths = records.save_records(str(tmp_path / 'single'), [f'{i}.png' for i in range(B)], fit)
+    assert [os.path.basename(p) for p in paths] == ['0.png.npz', '1.png.npz', '2.png.npz']
+    full, be, cam_ws = records.warm_start(paths, dev)
+    assert full.shape == (B, 24, 3, 3) and be.shape == (B, 10) and cam_ws.shape == (B, 3)
+    assert torch.equal(full[:, 1:], fit.body_pose) and torch.equal(full[:, :1], fit.global_orient) and torch.equal(be, fit.betas)
+    np.testing.assert_allclose(cam_ws.cpu().numpy(), fit.cam_wp.cpu().numpy(), rtol=3e-6)
+    a = single_view_optimization(smpl_gpu, full[:, 1:], full[:, :1], be, cam_ws, tgt, interation=1)
+    b = single_view_optimization(smpl_gpu, fit.body_pose, fit.global_orient, fit.betas, fit.cam_wp, tgt, interation=1)
+    np.testing.assert_allclose(a.body_pose.cpu().numpy(), b.body_pose.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(a.cam_wp.cpu().numpy(), b.cam_wp.cpu().numpy(), atol=2e-5)
 
 
 # ---------------------------------------------------------------- regressor (a2-a4)
