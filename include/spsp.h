@@ -152,6 +152,16 @@ int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, int precision
 int spsp_proxy_build(spsp_ctx* ctx, const void* silhouettes, int sil_format, const float* joints2d, int joints_stride,
                      int B, int precision, void* native_out, void* stream);
 
+/* Front half of the proxy builder: the detected boxes of ONE frame -> 512 x 512 player crops (replaces crop_image,
+ * S/global_utils.py:257-290, + cv2.resize(..., player_crop_size, INTER_LINEAR), S/PlayerDetection/player_detection.py:
+ * 181-184, for all boxes in one launch).  frame: device [H,W,3] uint8 (BGR, as cv2.imread returns it); boxes: device
+ * [N,4] int32 (x0, y0, x1, y1 -- the detector's boxes after astype(int32), player_detection.py:30); border:
+ * player_crop_border (40) or player_crop_border_broad (15); crops: device [N,out_wh,out_wh,3] uint8.  The box grows by
+ * `border`, is clamped to the frame, padded to a square with BGR (53, 88, 83) and resized with OpenCV's 8-bit bilinear
+ * arithmetic (restated in csrc/crop.hip; OpenCV itself is an un-vendored dependency of the reference). */
+int spsp_crop_players(spsp_ctx* ctx, const uint8_t* frame, int H, int W, const int32_t* boxes, int N, int border, int out_wh,
+                      uint8_t* crops, void* stream);
+
 /* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
                            float* cam, float* pose6d, float* betas, float* feats, void* stream);

@@ -93,3 +93,66 @@ def create_proxy_representation(silhouette, joints2D, in_wh, out_wh):
     hm = gaussian_heatmaps(j.astype(np.int16), out_wh)
     proxy = np.concatenate([sil[:, :, None], hm], axis=-1)
     return np.transpose(proxy, [2, 0, 1])
+
+
+# ---------------------------------------------------------------- front half of the proxy builder
+CROP_FILL_BGR = (53, 88, 83)          # S/global_utils.py:288
+
+
+def crop_image(image, box, border):
+    """`S/global_utils.py:257-290` with `cv2.copyMakeBorder(..., BORDER_CONSTANT, value=(53, 88, 83))` written out."""
+    left, top, right, bottom = box[0] - border, box[1] - border, box[2] + border, box[3] + border
+    left, top = max(left, 0), max(top, 0)
+    right, bottom = min(right, image.shape[1]), min(bottom, image.shape[0])
+    croped = image[top:bottom, left:right]
+    size = max(croped.shape[0], croped.shape[1])
+    if size == croped.shape[0]:
+        diff = size - croped.shape[1]
+        pad_top = pad_bottom = 0
+        pad_left = pad_right = diff // 2
+        if diff % 2 != 0:
+            pad_left += 1
+    else:
+        diff = size - croped.shape[0]
+        pad_left = pad_right = 0
+        pad_top = pad_bottom = diff // 2
+        if diff % 2 != 0:
+            pad_top += 1
+    ans = np.empty((croped.shape[0] + pad_top + pad_bottom, croped.shape[1] + pad_left + pad_right, 3), dtype=image.dtype)
+    ans[:] = np.array(CROP_FILL_BGR, dtype=image.dtype)
+    ans[pad_top:pad_top + croped.shape[0], pad_left:pad_left + croped.shape[1]] = croped
+    return ans
+
+
+def resize_linear_u8(src, dsize):
+    """`cv2.resize(src, (dsize, dsize), interpolation=cv2.INTER_LINEAR)` for 8-bit images, restated from OpenCV's
+    published source (modules/imgproc/src/resize.cpp; OpenCV is absent here and un-pinned in the reference: unpinned):
+    coordinate f = (float)((d + 0.5) * scale - 0.5) with scale = 1 / (dsize / ssize) in double, clamped taps, 11-bit
+    fixed-point coefficients (cvRound = round half to even), rows first in exact integers, columns in the 16-bit SIMD
+    form ((b0 (H0 >> 4)) >> 16) + ((b1 (H1 >> 4)) >> 16) + 2) >> 2; an exact 2 x 2 shrink takes the INTER_AREA path."""
+    ssize = src.shape[0]
+    assert src.shape[0] == src.shape[1] and src.dtype == np.uint8
+    if ssize == 2 * dsize:
+        s = src.astype(np.int32)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    scale = 1.0 / (float(dsize) / float(ssize))
+    d = np.arange(dsize, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo, hi = s < 0, s >= ssize - 1
+    s = np.where(lo, 0, np.where(hi, ssize - 1, s))
+    f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+    a1 = np.rint(f * np.float32(2048)).astype(np.int64)              # np.rint: half to even, like cvRound
+    a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    s1 = np.minimum(s + 1, ssize - 1)
+    S = src.astype(np.int64)
+    H = S[:, s, :] * a0[None, :, None] + S[:, s1, :] * a1[None, :, None]          # [ssize, dsize, 3]
+    H0, H1 = H[s], H[s1]
+    out = (((a0[:, None, None] * (H0 >> 4)) >> 16) + ((a1[:, None, None] * (H1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def crop_players(image, boxes, border, dsize=512):
+    """What `S/PlayerDetection/player_detection.py:181-184` produces for every detected box of a frame."""
+    return np.stack([resize_linear_u8(crop_image(image, [int(v) for v in b], border), dsize) for b in boxes])

@@ -135,6 +135,7 @@ _PROTOS = {
     'spsp_relate_free': (None, [_vp]),
     'spsp_relate_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     'spsp_proxy_build': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'spsp_crop_players': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spsp_regressor_read_stage': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     'spsp_rot6d_to_rotmat': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),

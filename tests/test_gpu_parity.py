@@ -283,7 +283,7 @@ def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev
             # ... and back to disk in the multi-view layout (:1976-1979)
             d = str(tmp_path / f'out_p{b}_V{V}_{int(optimise_body_pose)}')
             records.save_multiview_record(d, out.body_pose[b:b + 1], out.betas[b:b + 1],
-                                          {f'view{v}.png': (out.translation[b, v:v + 1], out.global_orient[b, v]) for v in range(V)})
+                                          {f'view{v}.png': (out.translation[b, v:v + 1], out.global_orient[b, v][None]) for v in range(V)})
             bp, be, vs = records.load_multiview_record(d)
             assert np.array_equal(bp[0], out.body_pose[b].cpu().numpy()) and len(vs) == V
     with pytest.raises(ValueError):
@@ -603,6 +603,32 @@ def test_smpl_forward_is_bit_stable_next_to_convolutions_on_other_streams(regres
         bad += sum(0 if (torch.equal(o.vertices, ref_v) and torch.equal(o.joints, ref_j)) else 1 for o in outs)
         assert all(torch.equal(f, feats_ref) for f in feats)
     assert bad == 0, f'{bad} of {total} SMPL forwards differ from the serial result while convolutions run on other streams'
+
+
+# ---------------------------------------------------------------- box -> crop -> pad -> bilinear 512 on the GPU (8f-1, front half)
+def test_gpu_player_crops_are_bit_identical_to_the_restated_crop_image_and_cv2_resize(dev):
+    """spsp_crop_players vs the numpy restatement of `crop_image` (S/global_utils.py:257-290) + OpenCV's 8-bit
+    INTER_LINEAR (oracle/geometry.py): every byte of every crop -- boxes inside the 1080p frame, boxes whose border
+    leaves it on each side, odd and even padding on both axes, the 512 identity, the exact 2 x 2 shrink (INTER_AREA
+    path), strong up-scaling of a tiny box, and a box wider than tall."""
+    from soccerplayershapepose_amd.global_utils import crop_players, player_crop_border, player_crop_border_broad
+    from oracle import geometry as G
+    rng = np.random.default_rng(11)
+    frame = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    boxes = np.array([[900, 400, 980, 640], [3, 5, 90, 300], [1850, 800, 1919, 1079], [700, 0, 761, 177], [100, 200, 612, 712],
+                      [10, 20, 1034, 1044], [1000, 500, 1003, 503], [300, 900, 900, 1000], [640, 300, 741, 523], [5, 1000, 400, 1075]],
+                     dtype=np.float32) + 0.6          # detector boxes are floats; astype(int32) truncates (player_detection.py:30)
+    for border in (player_crop_border, player_crop_border_broad, 0):
+        got = crop_players(torch.from_numpy(frame).to(dev), boxes, border=border)
+        ref = G.crop_players(frame, boxes.astype(np.int32), border)
+        assert got.shape == (len(boxes), 512, 512, 3) and got.dtype == torch.uint8
+        diff = (got.cpu().numpy().astype(np.int16) - ref.astype(np.int16))
+        assert np.abs(diff).max() == 0, f'border {border}: {int((diff != 0).sum())} bytes differ (max {np.abs(diff).max()})'
+    # the 512 identity crop is the frame region itself; an empty box list is a no-op
+    np.testing.assert_array_equal(crop_players(frame, boxes[4:5], border=0)[0].cpu().numpy(), frame[200:712, 100:612])
+    assert crop_players(frame, np.zeros((0, 4), np.float32)).shape == (0, 512, 512, 3)
+    with pytest.raises(ValueError):
+        crop_players(frame.astype(np.float32), boxes)
 
 
 # ---------------------------------------------------------------- proxy builder on the GPU (8f-1)
