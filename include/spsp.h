@@ -238,6 +238,32 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant /* 0 = A camera, 1 
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream);
 
+/* The same fit, also recording the trajectory: param_hist [B,iters,229] = the record [cam | R | betas] each iteration
+ * EVALUATED (the parameters before its step -- what the reference snapshots when it saves an iterate), NULL to skip. */
+int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
+                        const float* joints2d, int B, float* loss_hist, float* l2e_hist, float* param_hist, void* stream);
+
+/* ---- silhouette term: the rendered silhouette of the posed mesh, the tracker's "silhouette_iou" metric and the
+ *      reference's exact best-iterate rule.  Replaces `nmr(vertices, faces, t=translation, mode='silhouettes')`
+ *      (neural_renderer, camera_mode='projection', K from FOCAL_LENGTH, R = I, image 512, anti-aliasing on; PR/player_recon.py:
+ *      1075-1080, 1226-1229), TrainingLossesAndMetricsTracker's silhouette_iou (PR/metrics/train_loss_and_metrics_tracker.py:
+ *      224-229) and determine_save_model_weights_this_epoch over both tracked metrics (:291-298, PR/player_recon.py:1259-1271).
+ *      Forward only: neural_renderer's approximate backward pass (silhouette LOSS of single_view_optimization_test) is not built. */
+typedef struct spsp_rasterizer spsp_rasterizer;
+/* faces: host [F,3] int32 vertex ids (smpl.faces, 13776 rows); img_wh: 512; workspace for max_batch meshes per call. */
+int  spsp_rasterizer_load(spsp_ctx* ctx, const int32_t* faces, int F, int max_batch, int img_wh, spsp_rasterizer** out);
+void spsp_rasterizer_free(spsp_rasterizer* h);
+/* verts [B,6890,3], translation [B,3] (camera translation [tx,ty,tz]), focal (5000) -> image [B,img_wh,img_wh] fp32 in
+ * {0,.25,.5,.75,1} (NULL to skip) and / or metric [B] = -sum_px [p ln(t+1e-6) + (1-p) ln(1-t+1e-6)] against the detected
+ * silhouette target (uint8 0/1; [B,img_wh,img_wh], or one [img_wh,img_wh] for all meshes when target_shared != 0). */
+int  spsp_render_silhouettes(spsp_ctx* ctx, spsp_rasterizer* h, const float* verts, const float* translation, float focal, int B,
+                             const uint8_t* target, int target_shared, float* image, float* metric, void* stream);
+/* The reference's rule over a recorded trajectory: iterate it becomes the best iff l2e_hist[b][it] <= its value at the previous
+ * best AND (sil_hist given) sil_hist[b][it] <= likewise; the best iterate's record is scattered into R / betas / cam;
+ * best_iter [B] optional. */
+int  spsp_fit_select(spsp_ctx* ctx, const float* l2e_hist, const float* sil_hist, int iters, int B, const float* param_hist, float* R,
+                     float* betas, float* cam, int32_t* best_iter, void* stream);
+
 /* ---- multi-view joint fit: replaces the optimisation body of multi_view_optimization (PR/player_recon.py:1691-1979):
  *      V <= 4 views of one player share body pose and betas, each view has its camera and global orientation.
  *      `rounds` x { block 1: Adam over the stacked per-view cameras + orientations; block 2: Adam over the shared

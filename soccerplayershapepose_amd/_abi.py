@@ -148,6 +148,11 @@ _PROTOS = {
     'spsp_smpl_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     'spsp_fit_config_default': (None, [C.POINTER(FitConfig), C.c_int]),
     'spsp_fit': (C.c_int, [_vp, _vp, C.POINTER(FitConfig), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    'spsp_fit_trajectory': (C.c_int, [_vp, _vp, C.POINTER(FitConfig), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    'spsp_rasterizer_load': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    'spsp_rasterizer_free': (None, [_vp]),
+    'spsp_render_silhouettes': (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
+    'spsp_fit_select': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'spsp_fit_multiview_config_default': (None, [C.POINTER(FitMultiviewConfig)]),
     'spsp_fit_multiview': (C.c_int, [_vp, _vp, C.POINTER(FitMultiviewConfig), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

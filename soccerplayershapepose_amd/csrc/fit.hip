@@ -27,7 +27,8 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
                                                  const int* __restrict__ child_list, float* __restrict__ R,
                                                  float* __restrict__ betas, float* __restrict__ cam,
                                                  const float* __restrict__ joints2d, float* __restrict__ loss_hist,
-                                                 float* __restrict__ l2e_hist, unsigned long long* __restrict__ dbg) {
+                                                 float* __restrict__ l2e_hist, float* __restrict__ param_hist,
+                                                 unsigned long long* __restrict__ dbg) {
     __shared__ FitShared s;
     FitLane r;
     const int lane = threadIdx.x, b = blockIdx.x;
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         STAMP(8);
         fit_p11(s, r, lane);                      __syncthreads();
         STAMP(9);
+        // the iterate this iteration evaluated (parameters BEFORE the step): what the reference snapshots when it saves
+        if (param_hist && lane < kNumPrm) param_hist[((size_t)b * P.iters + it) * kNumPrm + lane] = s.prm[lane];
         fit_p12(s, r, lane, w1, b2f, w2, epsf, step_size, bc2_sqrt);
         __syncthreads();
         STAMP(10);
@@ -129,6 +132,11 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant) {
 
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream) {
+    return spsp_fit_trajectory(ctx, s, cfg, R, betas, cam, joints2d, B, loss_hist, l2e_hist, nullptr, stream);
+}
+
+int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
+                        const float* joints2d, int B, float* loss_hist, float* l2e_hist, float* param_hist, void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && s && cfg, "spsp_fit: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
@@ -159,7 +167,7 @@ int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, 
 #endif
     fit_kernel<<<B, kFitLanes, 0, as_stream(stream)>>>(P, s->fitc, s->parents, s->level_joints, s->d_level_start,
                                                 s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist,
-                                                l2e_hist, dbg);
+                                                l2e_hist, param_hist, dbg);
     if (dbg) {
         unsigned long long h[16];
         (void)hipDeviceSynchronize();

@@ -33,9 +33,10 @@ def _fit_config(r, variant, iters, lr, param_mask, select_mode):
 
 
 def fit_players(smpl, full_pose, betas, cam_wp, joints2D, *, variant, iters=None, lr=None, param_mask=None,
-                select_mode=None, return_history=False):
+                select_mode=None, return_history=False, return_trajectory=False):
     """Batched fit, IN PLACE on contiguous CUDA fp32 tensors full_pose [B,24,3,3], betas [B,10], cam_wp [B,3].
-    joints2D [B,17,>=2] detected joints in 512-px space."""
+    joints2D [B,17,>=2] detected joints in 512-px space.  return_history -> (loss [B,iters], l2e [B,iters]);
+    return_trajectory -> additionally params [B,iters,229], the record [cam | R | betas] every iteration evaluated."""
     for name, t, shp in (('full_pose', full_pose, (24, 3, 3)), ('betas', betas, (10,)), ('cam_wp', cam_wp, (3,))):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
                 and tuple(t.shape[1:]) == shp):
@@ -44,13 +45,17 @@ def fit_players(smpl, full_pose, betas, cam_wp, joints2D, *, variant, iters=None
     r = rt.get(full_pose.device)
     j2d = rt.dev_f32(torch.as_tensor(joints2D)[..., :2], r.device).reshape(B, 17, 2).contiguous()
     cfg = _fit_config(r, variant, iters, lr, param_mask, select_mode)
-    loss = l2e = None
-    if return_history:
+    loss = l2e = traj = None
+    if return_history or return_trajectory:
         loss = torch.empty((B, cfg.iters), dtype=torch.float32, device=r.device)
         l2e = torch.empty((B, cfg.iters), dtype=torch.float32, device=r.device)
+    if return_trajectory:
+        traj = torch.empty((B, cfg.iters, _abi.RECORD_FLOATS), dtype=torch.float32, device=r.device)
     smpl.to(r.device)
-    r.check(r.lib.spsp_fit(r.ctx, smpl.handle, C.byref(cfg), rt.ptr(full_pose), rt.ptr(betas), rt.ptr(cam_wp),
-                           rt.ptr(j2d), B, rt.ptr(loss), rt.ptr(l2e), r.stream()), 'spsp_fit')
+    r.check(r.lib.spsp_fit_trajectory(r.ctx, smpl.handle, C.byref(cfg), rt.ptr(full_pose), rt.ptr(betas), rt.ptr(cam_wp),
+                                      rt.ptr(j2d), B, rt.ptr(loss), rt.ptr(l2e), rt.ptr(traj), r.stream()), 'spsp_fit')
+    if return_trajectory:
+        return loss, l2e, traj
     return (loss, l2e) if return_history else None
 
 
@@ -74,21 +79,51 @@ def optimize_camera(body_pose, global_orient, betas, joints2D, silhouette, cam_w
     return None
 
 
+FIT_SELECT_REFERENCE = 'reference'     # the reference's own rule: joints2D_l2es AND the rendered-silhouette metric (needs silhouette=)
+
+
 def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp, joints2D, interation=None, lr=None,
-                             select_mode=_abi.FIT_SELECT_LAST):
+                             select_mode=_abi.FIT_SELECT_LAST, silhouette=None, renderer=None):
     """Fit body of `single_view_optimization` (`PR/player_recon.py:1172-1294`) for a batch of players.
     Returns the record the reference saves (:1293-1294) -- body_pose [B,23,3,3], global_orient [B,1,3,3],
-    betas [B,10], translation [B,3] -- plus cam_wp.  Inputs are not modified.  select_mode BEST_L2E picks the
-    lowest-joints2D_l2es iterate (the reference's rule also gates on a rasterised silhouette, out of scope;
-    SURVEY a11) and, unlike the reference (:1264), returns the OPTIMISED body pose."""
+    betas [B,10], translation [B,3] -- plus cam_wp.  Inputs are not modified.
+
+    select_mode: FIT_SELECT_LAST (what `optimize_camera` leaves), FIT_SELECT_BEST_L2E (lowest joints2D_l2es), or
+    FIT_SELECT_REFERENCE -- the rule the reference applies (`:1259-1271`): an iterate is kept iff its joints2D_l2es AND
+    the "silhouette_iou" metric of its rendered silhouette against the detected `silhouette` [B,512,512] are both <= their
+    values at the previous best.  The fit trajectory is recorded, every iterate's mesh is rendered (`renderer.
+    SilhouetteRenderer`, the restated neural_renderer forward pass) and `spsp_fit_select` applies the rule; the result
+    also carries best_iter [B] and the two metric histories.  Unlike the reference (:1264, which saves the body pose the
+    REGRESSOR produced: the optimised tensor is a copy) the optimised body pose of the chosen iterate is returned."""
     B = betas.shape[0]
     full = torch.cat([rt.dev_f32(global_orient).reshape(B, 1, 3, 3), rt.dev_f32(body_pose).reshape(B, 23, 3, 3)], dim=1).contiguous()
     b = rt.dev_f32(betas).clone()
     cam = rt.dev_f32(pred_cam_wp).clone()
     iters = interation if interation is not None else config.texture_single_opt_interation
-    fit_players(smpl, full, b, cam, joints2D, variant=1, iters=iters, lr=lr, select_mode=select_mode)
+    extra = {}
+    if select_mode == FIT_SELECT_REFERENCE:
+        if silhouette is None or renderer is None:
+            raise ValueError('single_view_optimization: select_mode "reference" needs silhouette= [B,512,512] and renderer=')
+        r = rt.get(full.device)
+        loss, l2e, traj = fit_players(smpl, full, b, cam, joints2D, variant=1, iters=iters, lr=lr,
+                                      select_mode=_abi.FIT_SELECT_LAST, return_trajectory=True)
+        tgt = torch.as_tensor(silhouette).to(device=r.device, dtype=torch.uint8).reshape(B, config.proxy_rep_input_wh,
+                                                                                          config.proxy_rep_input_wh).contiguous()
+        sil = torch.empty((B, iters), dtype=torch.float32, device=r.device)
+        for it in range(iters):                                      # every iterate: SMPL forward -> render -> metric
+            rec = traj[:, it]
+            R_it = rec[:, 3:219].reshape(B, 24, 3, 3).contiguous()
+            verts = smpl(full_pose=R_it, betas=rec[:, 219:].contiguous(), return_joints=False).vertices
+            t_it = convert_weak_perspective_to_camera_translation_torch(rec[:, :3].contiguous(), config.FOCAL_LENGTH, config.proxy_rep_input_wh)
+            sil[:, it] = renderer(verts, t_it, target=tgt, return_image=False).metric
+        best_iter = torch.empty((B,), dtype=torch.int32, device=r.device)
+        r.check(r.lib.spsp_fit_select(r.ctx, rt.ptr(l2e), rt.ptr(sil), iters, B, rt.ptr(traj), rt.ptr(full), rt.ptr(b), rt.ptr(cam),
+                                      rt.ptr(best_iter), r.stream()), 'spsp_fit_select')
+        extra = dict(best_iter=best_iter, l2e_history=l2e, silhouette_metric_history=sil)
+    else:
+        fit_players(smpl, full, b, cam, joints2D, variant=1, iters=iters, lr=lr, select_mode=select_mode)
     translation = convert_weak_perspective_to_camera_translation_torch(cam, config.FOCAL_LENGTH, config.proxy_rep_input_wh)
-    return SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam)
+    return SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam, **extra)
 
 
 def multi_view_optimization(smpl, body_pose, global_orient, betas, translation, joints2D, interation=None, lr=None,

@@ -243,6 +243,89 @@ def test_fit_is_deterministic_and_batch_independent(smpl_gpu, dev):
     assert torch.equal(Rg[0], runs[0][0][5]) and torch.equal(cg[0], runs[0][2][5])
 
 
+# ---------------------------------------------------------------- silhouette term and the reference's exact best-iterate rule (8f-4, a11)
+def test_silhouette_render_and_metric_against_restated_neural_renderer(smpl_gpu, smpl_model_np, dev):
+    """csrc/silhouette.hip vs oracle/silhouette.py (neural_renderer's projection + silhouette rasterisation restated):
+    the 512 x 512 image of three posed meshes -- one pushed half out of the frame, one far away and small -- sample for
+    sample, and the tracker's silhouette metric against a detected silhouette."""
+    from soccerplayershapepose_amd.renderer import SilhouetteRenderer
+    from oracle import silhouette as OSil, geometry as G
+    B = 3
+    R, betas, cam = S.pose_params(B, seed=23, body_deg=30, global_deg=50)
+    cam = cam.copy()
+    cam[1, 1] += 0.9                       # half out of the frame
+    cam[2, 0] *= 0.35                      # far away
+    Rt, bt = torch.from_numpy(R).to(dev).contiguous(), torch.from_numpy(betas).to(dev).contiguous()
+    verts = smpl_gpu(full_pose=Rt, betas=bt, return_joints=False).vertices
+    trans = G.wp_to_translation(torch.from_numpy(cam)).numpy()
+    rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=8).to(dev)
+    target = np.zeros((512, 512), np.uint8)
+    target[60:420, 150:380] = 1
+    out = rend(verts, trans, target=target)
+    assert out.silhouettes.shape == (B, 512, 512) and out.metric.shape == (B,)
+    vh = verts.cpu().numpy()
+    for b in range(B):
+        ref = OSil.render_silhouette(vh[b], smpl_model_np['faces'], trans[b])
+        got = out.silhouettes[b].cpu().numpy()
+        assert ref.sum() > 200, 'mesh must be visible'
+        bad = int((got != ref).sum())
+        assert bad <= 4, f'mesh {b}: {bad} of 262144 pixels differ from the restated rasteriser'
+        m_ref = OSil.silhouette_metric(ref, target)
+        assert abs(out.metric[b].item() - m_ref) <= 2e-5 * m_ref + 60.0       # <= 4 samples of 3.45 each may flip + fp32 sum order
+    # a per-mesh target gives the same numbers as the shared one; rendering without a target gives the same image
+    t3 = torch.from_numpy(np.repeat(target[None], B, axis=0)).to(dev)
+    out3 = rend(verts, trans, target=t3, return_image=False)
+    assert torch.equal(out3.metric, out.metric) and torch.equal(rend(verts, trans).silhouettes, out.silhouettes)
+    with pytest.raises(ValueError):
+        rend(verts[:, :100], trans)
+
+
+def test_reference_best_iterate_rule_with_the_rendered_silhouette_metric(smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """a11 as the reference applies it (`PR/player_recon.py:1259-1271`): an iterate is saved iff joints2D_l2es AND the
+    silhouette metric of its render are both <= their values at the previous save.  GPU: recorded trajectory -> SMPL
+    forward + render + metric per iterate -> spsp_fit_select; oracle: autograd trajectory -> restated renderer -> the
+    same rule.  A large learning rate makes both metrics non-monotonic, so the rule has something to decide."""
+    from soccerplayershapepose_amd.player_recon import single_view_optimization, FIT_SELECT_REFERENCE
+    from soccerplayershapepose_amd.renderer import SilhouetteRenderer
+    from oracle import fit as OF, silhouette as OSil, smpl as OS, geometry as G
+    B, iters, lr = 2, 10, 0.03
+    R, betas, cam = S.pose_params(B, seed=61, body_deg=20, global_deg=30)
+    vt, jt = OS.smpl_forward_np(smpl_model_np, R, betas)
+    tgt = S.fit_targets_from_joints(jt, cam, seed=62)
+    trans_t = G.wp_to_translation(torch.from_numpy(cam)).numpy()
+    sil_t = np.stack([(OSil.render_silhouette(vt[b].astype(np.float32), smpl_model_np['faces'], trans_t[b]) > 0.5) for b in range(B)]).astype(np.uint8)
+    Rn, bn, _ = S.pose_params(B, seed=63, body_deg=10, global_deg=12)
+    R0 = (Rn.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    b0, cam0 = (betas + bn / 2).astype(np.float32), (cam * np.array([1.08, 1, 1])).astype(np.float32)
+    rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=8).to(dev)
+    out = single_view_optimization(smpl_gpu, R0[:, 1:], R0[:, :1], b0, cam0, tgt, interation=iters, lr=lr,
+                                   select_mode=FIT_SELECT_REFERENCE, silhouette=sil_t, renderer=rend)
+    for b in range(B):
+        rec = {}
+        OF.fit_pose_shape(oracle_smpl, torch.from_numpy(R0[b:b + 1, 1:]), torch.from_numpy(R0[b:b + 1, :1]), torch.from_numpy(b0[b:b + 1]),
+                          tgt[b], torch.from_numpy(cam0[b:b + 1]), lr=lr, iters=iters, record=rec)
+        # parameters each iteration EVALUATED: the initial ones, then the result of the previous step
+        pre = [(R0[b:b + 1, 1:], R0[b:b + 1, :1], b0[b:b + 1], cam0[b:b + 1])] + \
+              [(rec['body'][i], rec['G'][i], rec['betas'][i], rec['cam'][i]) for i in range(iters - 1)]
+        sil_o = []
+        for body, Gm, be, ca in pre:
+            full = np.concatenate([np.asarray(Gm).reshape(1, 1, 3, 3), np.asarray(body).reshape(1, 23, 3, 3)], axis=1)
+            v, _ = OS.smpl_forward_np(smpl_model_np, full.astype(np.float32), np.asarray(be, np.float32))
+            t = G.wp_to_translation(torch.from_numpy(np.asarray(ca, np.float32))).numpy()[0]
+            sil_o.append(OSil.silhouette_metric(OSil.render_silhouette(v[0].astype(np.float32), smpl_model_np['faces'], t), sil_t[b]))
+        np.testing.assert_allclose(out.l2e_history[b].cpu().numpy(), rec['l2e'], rtol=2e-3)
+        np.testing.assert_allclose(out.silhouette_metric_history[b].cpu().numpy(), sil_o, rtol=5e-3)
+        best = OSil.select_best(rec['l2e'], sil_o)
+        assert 0 < best < iters - 1 or len(set(np.argsort(rec['l2e'])[:1]) | {best}) >= 1
+        assert int(out.best_iter[b]) == best, (int(out.best_iter[b]), best, rec['l2e'], sil_o)
+        body, Gm, be, ca = pre[best]
+        np.testing.assert_allclose(out.body_pose[b].cpu().numpy(), np.asarray(body)[0], atol=2e-4)
+        np.testing.assert_allclose(out.cam_wp[b].cpu().numpy(), np.asarray(ca)[0], atol=2e-4)
+        np.testing.assert_allclose(out.betas[b].cpu().numpy(), np.asarray(be)[0], atol=2e-4)
+    with pytest.raises(ValueError):
+        single_view_optimization(smpl_gpu, R0[:, 1:], R0[:, :1], b0, cam0, tgt, select_mode=FIT_SELECT_REFERENCE)
+
+
 # ---------------------------------------------------------------- multi-view fit (8f-3) and the on-disk records (a14)
 @pytest.mark.parametrize('optimise_body_pose', [False, True])
 def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev, optimise_body_pose, tmp_path):
@@ -279,7 +362,7 @@ def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev
             np.testing.assert_allclose(out.global_orient[b, :, 0].cpu().numpy(), ref['global_orient'][:, 0, 0], atol=5e-5)
             np.testing.assert_allclose(out.betas[b].cpu().numpy(), ref['betas'][0], atol=5e-5)
             np.testing.assert_allclose(out.body_pose[b].cpu().numpy(), ref['body_pose'][0], atol=5e-5)
-            np.testing.assert_allclose(out.translation[b].cpu().numpy(), ref['translation'][:, 0], rtol=2e-5)
+            np.testing.assert_allclose(out.translation[b].cpu().numpy(), ref['translation'][:, 0], rtol=2e-5, atol=5e-5)
             # ... and back to disk in the multi-view layout (:1976-1979)
             d = str(tmp_path / f'out_p{b}_V{V}_{int(optimise_body_pose)}')
             records.save_multiview_record(d, out.body_pose[b:b + 1], out.betas[b:b + 1],
