@@ -169,7 +169,14 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
     if (s0 == 0)
         for (int i = tid; i < kHRowB / 16; i += 256) reinterpret_cast<uint4*>(hB + kHRowB)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    const uint32_t lane_off = 72 * frow + 16 * fq;            // pixel 16j + frow starts 72 (16j + frow) bytes into the row
+    // MFMA tile j = (span q = j >> 1, type t = j & 1) holds the conv columns 32q + 2t + {0,1, 4,5, 8,9, ...}: lane frow ->
+    // column 32q + 2t + 4 (frow >> 1) + (frow & 1).  With consecutive columns in consecutive lanes (72-byte pixel pitch, 8-byte
+    // bank slots s = 9 frow + 2 fq mod 32) lanes (0, fq=0) and (14, fq=1) of a half-wave always meet on a bank: every
+    // ds_read_b64 took two passes (measured: SQ_LDS_BANK_CONFLICT = 48 % of the LDS cycles, the K loop LDS-bound).  Taking
+    // the columns = 0,1 mod 4 in one tile and = 2,3 mod 4 in the other makes the 32 slots of a half-wave a permutation
+    // (the slot set {r : r mod 4 in {0,1}} and its shift by 2 partition Z32), for free: the tile's columns are a per-lane
+    // constant plus an immediate.  It also leaves every lane with a pooled column to produce (see the epilogue).
+    const uint32_t lane_off = 72 * (4 * (frow >> 1) + (frow & 1)) + 16 * fq;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
         // whole set in flight cannot be written (and scalar loads share the counter and return out of order).
 #define STEM_SB __builtin_amdgcn_sched_barrier(0);
 #define STEM_RD(G, J, KRN, KSN, LAST)                                                                     \
-        if (!(LAST)) xf[((G) + 1) & 1][J] = lds_read_2xb64<64 * (KSN) + 1152 * (J)>(xa[KRN]);
+        if (!(LAST)) xf[((G) + 1) & 1][J] = lds_read_2xb64<64 * (KSN) + 2304 * ((J) >> 1) + 144 * ((J) & 1)>(xa[KRN]);
 #define STEM_MM(G, J)                                                                                     \
         STEM_SB                                                                                           \
         acc[0][J] = Elem<F16>::mfma(wreg[0][G], xf[(G) & 1][J], acc[0][J]);                               \
@@ -217,10 +224,10 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
         STEM_SB                                                                                           \
     }
-        xf[0][0] = lds_read_2xb64<0>(xa[0]);        xf[0][1] = lds_read_2xb64<1152>(xa[0]);
-        xf[0][2] = lds_read_2xb64<2 * 1152>(xa[0]); xf[0][3] = lds_read_2xb64<3 * 1152>(xa[0]);
-        xf[0][4] = lds_read_2xb64<4 * 1152>(xa[0]); xf[0][5] = lds_read_2xb64<5 * 1152>(xa[0]);
-        xf[0][6] = lds_read_2xb64<6 * 1152>(xa[0]); xf[0][7] = lds_read_2xb64<7 * 1152>(xa[0]);
+        xf[0][0] = lds_read_2xb64<0>(xa[0]);            xf[0][1] = lds_read_2xb64<144>(xa[0]);
+        xf[0][2] = lds_read_2xb64<2304>(xa[0]);         xf[0][3] = lds_read_2xb64<2304 + 144>(xa[0]);
+        xf[0][4] = lds_read_2xb64<2 * 2304>(xa[0]);     xf[0][5] = lds_read_2xb64<2 * 2304 + 144>(xa[0]);
+        xf[0][6] = lds_read_2xb64<3 * 2304>(xa[0]);     xf[0][7] = lds_read_2xb64<3 * 2304 + 144>(xa[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STEM_SB
         //        G   sub-step G+1 = (KR, KS)
@@ -237,14 +244,15 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 #undef STEM_SB
 
         SSTAMP(3);
-        // ---- horizontal 3 -> 1 max in registers.  Lane (frow, fq) of tile j holds conv column 16j + frow; pool column
-        // 8j + frow/2 (even frow) = max(columns 2p-1, 2p, 2p+1) = max(left neighbour, own, right neighbour).  The right
-        // neighbour of an even lane is lane+1 of the same DPP row; the left one is lane-1, or lane 15 of tile j-1 for
-        // lane 0 (column -1 of tile 0 is padding: the lane's own value stands in).  Odd lanes compute garbage.
-        // bias + ReLU + round to the element type FIRST (all monotone: max commutes with them), so that the pool runs on 32
-        // packed registers instead of 64 floats: v_pk_max_u16 -- post-ReLU values are >= +0, and for bf16 and fp16 alike the
-        // numeric order of non-negative values is the order of their 16-bit patterns.
+        // ---- horizontal 3 -> 1 max in registers.  bias + ReLU + round to the element type FIRST (all monotone: max commutes
+        // with them), so that the pool runs on packed registers with v_pk_max_u16 -- post-ReLU values are >= +0, and for bf16
+        // and fp16 alike the numeric order of non-negative values is the order of their 16-bit patterns.
+        // Span q: tile a = type 0 (lane n: column 4 (n>>1) + (n&1)), tile b = type 1 (the same + 2).  Pool column 16q + n:
+        //   even n = 2m:  max(col 4m-1, 4m, 4m+1) = max(b[n-1], a[n], a[n+1])      (b[-1] = lane 15 of the previous span's b;
+        //   odd  n = 2m+1: max(col 4m+1, 4m+2, 4m+3) = max(a[n], b[n-1], b[n])      column -1 is padding: a[0] stands in)
+        // so EVERY lane ends with one pooled column: three DPP moves, one select and two packed max per register.
         unsigned char* const hrow = r == 0 ? hA : hB + (s & 1) * kHRowB;
+        const bool odd = frow & 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float bv[4] = {bias_r[i].x, bias_r[i].y, bias_r[i].z, bias_r[i].w};
@@ -256,22 +264,20 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
                 P[j][1] = Elem<F16>::pack2(fmaxf(c[2] + bv[2], 0.f), fmaxf(c[3] + bv[3], 0.f));
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int q = 0; q < 4; ++q) {
                 uint32_t m[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const uint32_t v = P[j][k];
-                    const uint32_t right = dpp<kDppShl1>(v, v);
-                    const uint32_t wrap = j > 0 ? dpp<kDppRor1>(v, P[j > 0 ? j - 1 : 0][k]) : v;     // lane 0 <- lane 15 of tile j-1
-                    const uint32_t left = dpp<kDppShr1>(wrap, v);                                     // lanes 1..15 <- lane-1; lane 0 keeps `wrap`
-                    m[k] = pk_max_u16(pk_max_u16(v, right), left);
+                    const uint32_t va = P[2 * q][k], vb = P[2 * q + 1][k];
+                    const uint32_t wrap = q > 0 ? dpp<kDppRor1>(va, P[q > 0 ? 2 * q - 1 : 0][k]) : va;   // lane 0 <- lane 15 of the previous span's b
+                    const uint32_t bl = dpp<kDppShr1>(wrap, vb);                                         // b[n-1]; lane 0 keeps `wrap`
+                    const uint32_t ar = dpp<kDppShl1>(va, va);                                           // a[n+1]
+                    m[k] = pk_max_u16(pk_max_u16(va, bl), odd ? vb : ar);
                 }
-                if (!(frow & 1)) {
-                    const int px = 8 * j + (frow >> 1);
-                    // [px][64 ch] with the 8-byte slot index XORed by 2 (px & 7): the 8 active lanes of a DPP row hit 8 bank groups
-                    const int slot = (8 * h + 4 * i + fq) ^ (2 * (px & 7));
-                    *reinterpret_cast<uint2*>(hrow + px * 128 + slot * 8) = make_uint2(m[0], m[1]);
-                }
+                const int px = 16 * q + frow;
+                // [px][64 ch] with the 8-byte slot index XORed by 2 (px & 7)
+                const int slot = (8 * h + 4 * i + fq) ^ (2 * (px & 7));
+                *reinterpret_cast<uint2*>(hrow + px * 128 + slot * 8) = make_uint2(m[0], m[1]);
             }
         }
         SSTAMP(4);
