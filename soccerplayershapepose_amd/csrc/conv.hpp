@@ -31,9 +31,9 @@ struct ConvArgs {
     unsigned int* counter;   // conv_wres: device word, zero before the launch -- dynamic tile scheduler (atomicAdd)
     int f16;                 // element type of in / w / res / out: 0 = bf16, 1 = fp16 (conv_elem.hpp)
     int xcd_n;               // conv_patch: XCDs along the channel blocks (tile order; set by launch_conv_patch)
-    // conv_ring: an optional SECOND convolution in the same launch -- the 1x1 stride-2 downsample of a residual stage rides
-    // with the stage's 3x3 stride-2 conv: same input pixels (the 3x3's centre tap), same output geometry, N2 more channel
-    // blocks whose K loop covers only the centre-tap steps.  w2 = [n2][chunks*64], no residual, no ReLU.
+    // conv_ring: an optional SECOND convolution by the same workgroups -- the 1x1 stride-2 downsample of a residual stage rides
+    // with the stage's 3x3 stride-2 conv: same input pixels (the 3x3's centre tap), same output geometry and channel count;
+    // `chunks` extra K-steps into a second accumulator set.  w2 = [n2][chunks*64], no residual, no ReLU.
     const uint16_t* w2;
     const float* bias2;
     uint16_t* out2;

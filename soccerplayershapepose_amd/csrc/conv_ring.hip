@@ -55,21 +55,18 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int HoWo = a.Ho * a.Wo;
 
-    // tile order: XCD-contiguous (see conv.hip)
-    const int mt = a.M / BM, nb1 = a.N / BN;
-    const int ntiles = mt * (nb1 + a.n2 / BN);
+    // tile order: XCD-contiguous
+    const int mt = a.M / BM;
+    const int ntiles = mt * (a.N / BN);
     int tile = blockIdx.x;
     if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
-    const int m_blk = (tile % mt) * BM;
-    // channel blocks past N belong to the second convolution (the 1x1 downsample): only the centre-tap K-steps
-    const bool second = tile / mt >= nb1;
-    const int n_blk = (tile / mt - (second ? nb1 : 0)) * BN;
-    const int step_lo = second ? 4 * a.chunks : 0, nsteps = second ? a.chunks : a.nsteps;
-    const uint16_t* const w_ptr = second ? a.w2 : a.w;
-    const float* const bias_ptr = second ? a.bias2 : a.bias;
-    uint16_t* const out_ptr = second ? a.out2 : a.out;
-    const uint16_t* const res_ptr = second ? nullptr : a.res;
-    const int relu = second ? 0 : a.relu;
+    const int m_blk = (tile % mt) * BM, n_blk = (tile / mt) * BN;
+    // Optional SECOND convolution on the same pixels (a.n2 == a.N channels): the 1x1 stride-2 downsample of a residual stage
+    // rides with the stage's 3x3 stride-2 conv.  Its input pixels are the 3x3's centre tap, so the workgroup simply runs
+    // `chunks` more K-steps behind the 9 * chunks of the 3x3 -- pixel rows of the centre tap again, weight slabs from w2,
+    // a second accumulator set -- through the same ring (the prefetch runs across the seam), and stores two tiles.
+    const bool dual = a.n2 > 0;
+    const int n1 = a.nsteps, nsteps = n1 + (dual ? a.chunks : 0);
 
     // ---- LDS-DMA sources: lane l of instruction i feeds LDS row (wave*ROWS/4 + i*8 + l/8), physical chunk l%8,
     //      i.e. logical chunk (l%8) ^ (row%8) of that row ----
@@ -83,32 +80,36 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
         a_src[i] = a.in + a.in_off + (size_t)b * a.in_img + ho * a.stride * a.in_row + wo * a.stride * a.in_pix +
                    ((dchunk ^ (row & 7)) * 8);
     }
-    const int Ktot = nsteps * BK;
+    const int Ktot = n1 * BK, Ktot2 = a.chunks * BK;
     const uint16_t* b_src[IB];
+    const uint16_t* b2_src[IB];
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
         const int row = wave * (BN / 4) + i * 8 + drow;
-        b_src[i] = w_ptr + (size_t)(n_blk + row) * Ktot + ((dchunk ^ (row & 7)) * 8) - (size_t)step_lo * BK;   // indexed by the 3x3's step number
+        b_src[i] = a.w + (size_t)(n_blk + row) * Ktot + ((dchunk ^ (row & 7)) * 8);
+        b2_src[i] = dual ? a.w2 + (size_t)(n_blk + row) * Ktot2 + ((dchunk ^ (row & 7)) * 8) : b_src[i];
     }
     const int in_row = a.in_row, in_pix = a.in_pix, kw_steps = a.kw_steps, chunks = a.chunks;
 
     auto issue = [&](int gstep, int buf) {
+        const bool second = gstep >= n1;                       // centre tap (r = c = 1 of the 3x3) + chunk gstep - n1
+        const int g = second ? 4 * chunks + (gstep - n1) : gstep;
         const int per_r = kw_steps * chunks;
-        const int r = gstep / per_r, rem = gstep - r * per_r, c = rem / chunks, ch = rem - c * chunks;
+        const int r = g / per_r, rem = g - r * per_r, c = rem / chunks, ch = rem - c * chunks;
         const int soff = r * in_row + c * in_pix + ch * BK;
         unsigned char* sa = smem + buf * STAGE + wave * (BM / 4) * ROWB;
         unsigned char* sb = smem + buf * STAGE + BM * ROWB + wave * (BN / 4) * ROWB;
 #pragma unroll
         for (int i = 0; i < IA; ++i) dma16(a_src[i] + soff, sa + i * 8 * ROWB);
 #pragma unroll
-        for (int i = 0; i < IB; ++i) dma16(b_src[i] + (size_t)gstep * BK, sb + i * 8 * ROWB);
+        for (int i = 0; i < IB; ++i) dma16(second ? b2_src[i] + (size_t)(gstep - n1) * BK : b_src[i] + (size_t)gstep * BK, sb + i * 8 * ROWB);
     };
 
-    f32x4 acc[NT][MT];
+    f32x4 acc[NT][MT], acc2[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // fragment read addresses: row = region + t*16 + frow, chunk (ks*4 + fq) ^ (frow & 7)  (region bases are
     // multiples of 16 rows, so row & 7 == frow & 7); ks = 1 flips byte-offset bit 6.
@@ -119,47 +120,47 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
     const uint32_t wb0 = smem_base + BM * ROWB + wn * (BN / 2) * ROWB;   // this wave's weight rows
 
     int issued = 0;
-    for (; issued < NS - 1 && issued < nsteps; ++issued) issue(step_lo + issued, issued);
+    for (; issued < NS - 1 && issued < nsteps; ++issued) issue(issued, issued);
 
-    for (int s = 0; s < nsteps; ++s) {
-        const int ahead = issued - (s + 1);            // stages in flight behind the one we are about to read
-        if (ahead >= 2) wait_vmcnt<2 * LPS>();
-        else if (ahead == 1) wait_vmcnt<LPS>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (issued < nsteps) { issue(step_lo + issued, issued % NS); ++issued; }
-
-        const uint32_t so = (uint32_t)((s % NS) * STAGE);
-        bf16x8 wf[2][NT], xf[2][MT];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const uint32_t lo = lane_off ^ (ks * 64);
-            const uint32_t wa = wb0 + so + lo, pa = xa0 + so + lo;
-            wf[ks][0] = lds_read_b128<0>(wa);
-            if constexpr (NT > 1) wf[ks][1] = lds_read_b128<2048>(wa);
-            if constexpr (NT > 2) { wf[ks][2] = lds_read_b128<4096>(wa); wf[ks][3] = lds_read_b128<6144>(wa); }
-            xf[ks][0] = lds_read_b128<0>(pa);
-            if constexpr (MT > 1) xf[ks][1] = lds_read_b128<2048>(pa);
-            if constexpr (MT > 2) { xf[ks][2] = lds_read_b128<4096>(pa); xf[ks][3] = lds_read_b128<6144>(pa); }
-        }
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MT) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-                acc[i][j] = Elem<F16>::mfma(wf[0][i], xf[0][j], acc[i][j]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-                acc[i][j] = Elem<F16>::mfma(wf[1][i], xf[1][j], acc[i][j]);
+    // one K-step: wait for its stage, refill the ring, fragments, 2 x NT x MT MFMAs into ACC
+#define RING_STEP(S, ACC)                                                                              \
+    {                                                                                                  \
+        const int ahead = issued - ((S) + 1);          /* stages in flight behind the one about to be read */ \
+        if (ahead >= 2) wait_vmcnt<2 * LPS>();                                                         \
+        else if (ahead == 1) wait_vmcnt<LPS>();                                                        \
+        else wait_vmcnt<0>();                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        if (issued < nsteps) { issue(issued, issued % NS); ++issued; }                                 \
+        const uint32_t so = (uint32_t)(((S) % NS) * STAGE);                                            \
+        bf16x8 wf[2][NT], xf[2][MT];                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
+            const uint32_t lo = lane_off ^ (ks * 64);                                                  \
+            const uint32_t wa = wb0 + so + lo, pa = xa0 + so + lo;                                     \
+            wf[ks][0] = lds_read_b128<0>(wa);                                                          \
+            if constexpr (NT > 1) wf[ks][1] = lds_read_b128<2048>(wa);                                 \
+            if constexpr (NT > 2) { wf[ks][2] = lds_read_b128<4096>(wa); wf[ks][3] = lds_read_b128<6144>(wa); } \
+            xf[ks][0] = lds_read_b128<0>(pa);                                                          \
+            if constexpr (MT > 1) xf[ks][1] = lds_read_b128<2048>(pa);                                 \
+            if constexpr (MT > 2) { xf[ks][2] = lds_read_b128<4096>(pa); xf[ks][3] = lds_read_b128<6144>(pa); } \
+        }                                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MT) : "memory");                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < MT; ++j)                                             \
+                ACC[i][j] = Elem<F16>::mfma(wf[0][i], xf[0][j], ACC[i][j]);                            \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < MT; ++j)                                             \
+                ACC[i][j] = Elem<F16>::mfma(wf[1][i], xf[1][j], ACC[i][j]);                            \
     }
+    for (int s = 0; s < n1; ++s) RING_STEP(s, acc)
+    for (int s = n1; s < nsteps; ++s) RING_STEP(s, acc2)
+#undef RING_STEP
 
-    // ---- epilogue ----
-    {
+    // ---- epilogue(s): bias (+ residual) (+ ReLU) -> element type; a lane owns 4 channels of a pixel ----
+    auto store_tile = [&](f32x4 (&A)[NT][MT], const float* bias_ptr, const uint16_t* res_ptr, uint16_t* out_ptr, int relu, float* pool_out) {
         float psum[NT][4];
 #pragma unroll
         for (int i = 0; i < NT; ++i) psum[i][0] = psum[i][1] = psum[i][2] = psum[i][3] = 0.f;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
             for (int i = 0; i < NT; ++i) {
                 const int n = n_blk + wn * (BN / 2) + i * 16 + fq * 4;
                 const float4 bv = *reinterpret_cast<const float4*>(bias_ptr + n);
-                float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+                float v0 = A[i][j][0] + bv.x, v1 = A[i][j][1] + bv.y, v2 = A[i][j][2] + bv.z, v3 = A[i][j][3] + bv.w;
                 if (res_ptr) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(res_ptr + obase + n);
                     v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
                 psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
             }
         }
-        if (a.pool_out) {
+        if (pool_out) {
             __syncthreads();
             float* red = reinterpret_cast<float*>(smem);          // [2 (wm)][BN]
 #pragma unroll
@@ -196,10 +197,12 @@ __global__ __launch_bounds__(256) void conv_ring_kernel(const ConvArgs a) {
             __syncthreads();
             if (tid < BN) {
                 const int b = m_blk / HoWo;
-                a.pool_out[(size_t)b * a.N + n_blk + tid] = (red[tid] + red[BN + tid]) / (float)HoWo;
+                pool_out[(size_t)b * a.N + n_blk + tid] = (red[tid] + red[BN + tid]) / (float)HoWo;
             }
         }
-    }
+    };
+    store_tile(acc, a.bias, a.res, a.out, a.relu, a.pool_out);
+    if (dual) store_tile(acc2, a.bias2, nullptr, a.out2, 0, nullptr);
 }
 
 template <int BM, int BN, int NS, bool F16>
@@ -207,9 +210,9 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     SPSP_REQUIRE(a.N % BN == 0 && a.M % BM == 0, "conv_ring: M=%d N=%d not multiples of the %dx%d tile", a.M, a.N, BM, BN);
     SPSP_REQUIRE(a.in_pix % 8 == 0 && a.in_off % 8 == 0 && a.in_row % 8 == 0, "conv_ring: input not 16-byte aligned");
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-    SPSP_REQUIRE(a.n2 == 0 || (a.n2 % BN == 0 && a.w2 && a.bias2 && a.out2 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && !a.pool_out),
-                 "conv_ring: the second convolution must be a 1x1 riding on a 3x3 (n2 %% %d == 0)", BN);
-    const int tiles = (a.M / BM) * (a.N / BN + a.n2 / BN);
+    SPSP_REQUIRE(a.n2 == 0 || (a.n2 == a.N && a.w2 && a.bias2 && a.out2 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && !a.pool_out),
+                 "conv_ring: the second convolution must be a 1x1 with the 3x3's channel count riding on it");
+    const int tiles = (a.M / BM) * (a.N / BN);
     SPSP_REQUIRE(!a.pool_out || BM == a.Ho * a.Wo, "conv_ring: fused avg-pool needs one image per M tile");
     SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, F16>>((int)lds)));
     conv_ring_kernel<BM, BN, NS, F16><<<dim3(tiles), 256, lds, st>>>(a);

@@ -92,7 +92,8 @@ struct StemArgs {
     unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of one workgroup
 };
 
-template <bool F16>
+// DIAG (diagnostic builds only, results invalid): 1 = no fragment reads in the K loop, 2 = no MFMAs -- what each stream costs alone
+template <bool F16, int DIAG = 0>
 __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const hA = smem + kRingB;                  // pooled conv row 2s   (wave row 0)
@@ -199,47 +200,69 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 #pragma unroll
         for (int kr = 0; kr < 7; ++kr) xa[kr] = smem_base + (uint32_t)(((n0 + 2 * r + kr) % kRing) * kPitch) + lane_off;
 
-        bf16x8 xf[2][8];
-        // sub-step G = 4 KR + KS: 16 MFMAs on fragment set G & 1.  The eight fragment reads of sub-step G+1 (kernel row KRN,
-        // quarter KSN) go out between the first four MFMA pairs of sub-step G, so that their issue slots and most of their
-        // latency sit under the matrix pipe; every sched_barrier pins that order (hipcc otherwise gathers the reads in
-        // front and sinks the register-only MFMAs below the wait).  A deeper look-ahead is not available: a fragment is
-        // two ds_read_b64 (8-byte aligned pixels), 16 per set, and lgkmcnt counts to 15 -- a counted wait that leaves a
-        // whole set in flight cannot be written (and scalar loads share the counter and return out of order).
+        bf16x8 xf[8];
+        // The K loop as ONE stream of 224 fragment / MFMA-pair slots (sub-step G = 4 KR + KS, tile J; slot number 8 G + J).
+        // Slot n: issue the two ds_read_b64 of the fragment SEVEN slots ahead into the register quad the previous slot has
+        // just consumed (xf[(J + 7) & 7]), wait until all but the 14 youngest LDS reads have returned -- exactly the
+        // fragment of slot n -- and issue its two MFMAs.  224 cycles of look-ahead at <= 14 reads in flight (lgkmcnt counts
+        // to 15); the per-sub-step form (all reads of G+1 during G, one lgkmcnt(0) at its end) left ~85 cycles of LDS
+        // latency exposed in every 256-cycle sub-step (K loop 9.5 k cycles for 7.2 k of MFMA).  Counted lgkmcnt waits need
+        // the counter to see LDS reads only: no scalar load may be in flight (they return out of order) -- the lgkmcnt(0)
+        // in front drains any, and the loop body issues none (checked in the ISA).
+        // Every sched_barrier pins the order (hipcc otherwise gathers the reads and sinks the register-only MFMAs).
 #define STEM_SB __builtin_amdgcn_sched_barrier(0);
-#define STEM_RD(G, J, KRN, KSN, LAST)                                                                     \
-        if (!(LAST)) xf[((G) + 1) & 1][J] = lds_read_2xb64<64 * (KSN) + 2304 * ((J) >> 1) + 144 * ((J) & 1)>(xa[KRN]);
-#define STEM_MM(G, J)                                                                                     \
+#define STEM_RD(J, KR, KS) xf[J] = lds_read_2xb64<64 * (KS) + 2304 * ((J) >> 1) + 144 * ((J) & 1)>(xa[KR]);
+#define STEM_SLOT(G, J, KRA, KSA, AHEAD, WAITN)                                                            \
+        if (AHEAD && DIAG != 1) { STEM_RD(((J) + 7) & 7, KRA, KSA) }                                       \
+        if (DIAG != 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WAITN) : "memory");                      \
         STEM_SB                                                                                           \
-        acc[0][J] = Elem<F16>::mfma(wreg[0][G], xf[(G) & 1][J], acc[0][J]);                               \
-        acc[1][J] = Elem<F16>::mfma(wreg[1][G], xf[(G) & 1][J], acc[1][J]);                               \
+        if (DIAG != 2) {                                                                                  \
+            acc[0][J] = Elem<F16>::mfma(wreg[0][G], xf[J], acc[0][J]);                                    \
+            acc[1][J] = Elem<F16>::mfma(wreg[1][G], xf[J], acc[1][J]);                                    \
+        } else { asm volatile("" : "+v"(xf[J])); }                                                        \
         STEM_SB
-#define STEM_STEP(G, KRN, KSN, LAST)                                                                      \
-    {                                                                                                     \
-        STEM_RD(G, 0, KRN, KSN, LAST) STEM_RD(G, 1, KRN, KSN, LAST) STEM_MM(G, 0)                          \
-        STEM_RD(G, 2, KRN, KSN, LAST) STEM_RD(G, 3, KRN, KSN, LAST) STEM_MM(G, 1)                          \
-        STEM_RD(G, 4, KRN, KSN, LAST) STEM_RD(G, 5, KRN, KSN, LAST) STEM_MM(G, 2)                          \
-        STEM_RD(G, 6, KRN, KSN, LAST) STEM_RD(G, 7, KRN, KSN, LAST) STEM_MM(G, 3)                          \
-        STEM_MM(G, 4) STEM_MM(G, 5) STEM_MM(G, 6) STEM_MM(G, 7)                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-        STEM_SB                                                                                           \
-    }
-        xf[0][0] = lds_read_2xb64<0>(xa[0]);            xf[0][1] = lds_read_2xb64<144>(xa[0]);
-        xf[0][2] = lds_read_2xb64<2304>(xa[0]);         xf[0][3] = lds_read_2xb64<2304 + 144>(xa[0]);
-        xf[0][4] = lds_read_2xb64<2 * 2304>(xa[0]);     xf[0][5] = lds_read_2xb64<2 * 2304 + 144>(xa[0]);
-        xf[0][6] = lds_read_2xb64<3 * 2304>(xa[0]);     xf[0][7] = lds_read_2xb64<3 * 2304 + 144>(xa[0]);
+        // sub-step G; (KR1, KS1) = coordinates of sub-step G+1 (slots J >= 1 read ahead into it, slot 0 still into G)
+#define STEM_STEP(G, KR0, KS0, KR1, KS1)                                                                  \
+        STEM_SLOT(G, 0, KR0, KS0, true, 14) STEM_SLOT(G, 1, KR1, KS1, true, 14) STEM_SLOT(G, 2, KR1, KS1, true, 14) \
+        STEM_SLOT(G, 3, KR1, KS1, true, 14) STEM_SLOT(G, 4, KR1, KS1, true, 14) STEM_SLOT(G, 5, KR1, KS1, true, 14) \
+        STEM_SLOT(G, 6, KR1, KS1, true, 14) STEM_SLOT(G, 7, KR1, KS1, true, 14)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STEM_SB
-        //        G   sub-step G+1 = (KR, KS)
-        STEM_STEP(0, 0, 1, false)  STEM_STEP(1, 0, 2, false)  STEM_STEP(2, 0, 3, false)  STEM_STEP(3, 1, 0, false)
-        STEM_STEP(4, 1, 1, false)  STEM_STEP(5, 1, 2, false)  STEM_STEP(6, 1, 3, false)  STEM_STEP(7, 2, 0, false)
-        STEM_STEP(8, 2, 1, false)  STEM_STEP(9, 2, 2, false)  STEM_STEP(10, 2, 3, false) STEM_STEP(11, 3, 0, false)
-        STEM_STEP(12, 3, 1, false) STEM_STEP(13, 3, 2, false) STEM_STEP(14, 3, 3, false) STEM_STEP(15, 4, 0, false)
-        STEM_STEP(16, 4, 1, false) STEM_STEP(17, 4, 2, false) STEM_STEP(18, 4, 3, false) STEM_STEP(19, 5, 0, false)
-        STEM_STEP(20, 5, 1, false) STEM_STEP(21, 5, 2, false) STEM_STEP(22, 5, 3, false) STEM_STEP(23, 6, 0, false)
-        STEM_STEP(24, 6, 1, false) STEM_STEP(25, 6, 2, false) STEM_STEP(26, 6, 3, false) STEM_STEP(27, 6, 3, true)
+        STEM_RD(0, 0, 0) STEM_RD(1, 0, 0) STEM_RD(2, 0, 0) STEM_RD(3, 0, 0) STEM_RD(4, 0, 0) STEM_RD(5, 0, 0) STEM_RD(6, 0, 0)
+        STEM_SB
+        STEM_STEP(0, 0, 0, 0, 1)
+        STEM_STEP(1, 0, 1, 0, 2)
+        STEM_STEP(2, 0, 2, 0, 3)
+        STEM_STEP(3, 0, 3, 1, 0)
+        STEM_STEP(4, 1, 0, 1, 1)
+        STEM_STEP(5, 1, 1, 1, 2)
+        STEM_STEP(6, 1, 2, 1, 3)
+        STEM_STEP(7, 1, 3, 2, 0)
+        STEM_STEP(8, 2, 0, 2, 1)
+        STEM_STEP(9, 2, 1, 2, 2)
+        STEM_STEP(10, 2, 2, 2, 3)
+        STEM_STEP(11, 2, 3, 3, 0)
+        STEM_STEP(12, 3, 0, 3, 1)
+        STEM_STEP(13, 3, 1, 3, 2)
+        STEM_STEP(14, 3, 2, 3, 3)
+        STEM_STEP(15, 3, 3, 4, 0)
+        STEM_STEP(16, 4, 0, 4, 1)
+        STEM_STEP(17, 4, 1, 4, 2)
+        STEM_STEP(18, 4, 2, 4, 3)
+        STEM_STEP(19, 4, 3, 5, 0)
+        STEM_STEP(20, 5, 0, 5, 1)
+        STEM_STEP(21, 5, 1, 5, 2)
+        STEM_STEP(22, 5, 2, 5, 3)
+        STEM_STEP(23, 5, 3, 6, 0)
+        STEM_STEP(24, 6, 0, 6, 1)
+        STEM_STEP(25, 6, 1, 6, 2)
+        STEM_STEP(26, 6, 2, 6, 3)
+        STEM_SLOT(27, 0, 6, 3, true, 14)
+        STEM_SLOT(27, 1, 6, 3, false, 12) STEM_SLOT(27, 2, 6, 3, false, 10) STEM_SLOT(27, 3, 6, 3, false, 8)
+        STEM_SLOT(27, 4, 6, 3, false, 6)  STEM_SLOT(27, 5, 6, 3, false, 4)  STEM_SLOT(27, 6, 6, 3, false, 2)
+        STEM_SLOT(27, 7, 6, 3, false, 0)
+#undef STEM_SLOT
 #undef STEM_STEP
-#undef STEM_MM
 #undef STEM_RD
 #undef STEM_SB
 
@@ -332,13 +355,18 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         (void)hipMalloc(&a.dbg, 16 * sizeof(unsigned long long));
-        if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+        const int diag = getenv("SPSP_STEM_DIAG") ? atoi(getenv("SPSP_STEM_DIAG")) : 0;
+        (void)ensure_dynamic_lds<&conv1_pool_kernel<true, 1>>(kLds);
+        (void)ensure_dynamic_lds<&conv1_pool_kernel<true, 2>>(kLds);
+        if (diag == 1) conv1_pool_kernel<true, 1><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+        else if (diag == 2) conv1_pool_kernel<true, 2><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+        else if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         else conv1_pool_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         (void)hipDeviceSynchronize();
         unsigned long long hh[16];
         (void)hipMemcpy(hh, a.dbg, sizeof hh, hipMemcpyDeviceToHost);
-        fprintf(stderr, "stem wg9 (band 1, 9 steps): prologue %llu | step3: K loop %llu | h-pool + LDS writes %llu | vmcnt/lgkm wait %llu | barrier %llu | vertical + stores %llu | barrier %llu | whole kernel %llu cycles\n",
-                hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
+        fprintf(stderr, "stem[diag %d] wg9 (band 1, 9 steps): prologue %llu | step3: K loop %llu | h-pool + LDS writes %llu | vmcnt/lgkm wait %llu | barrier %llu | vertical + stores %llu | barrier %llu | whole kernel %llu cycles\n",
+                diag, hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
         (void)hipFree(a.dbg);
         return SPSP_OK;
     }
