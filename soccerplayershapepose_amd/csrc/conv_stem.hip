@@ -52,15 +52,16 @@ __device__ __forceinline__ void dma16(const unsigned char* gsrc, unsigned char* 
 }
 
 constexpr int kRowB = 264 * 18 * 2;        // 9504 bytes of one native input row
-constexpr int kRowPieces = 10;             // 1-KiB LDS-DMA pieces per row (the last one re-reads the row's tail)
-constexpr int kPitch = kRowPieces * 1024;  // LDS row pitch
+constexpr int kRowPieces = 10;             // 1-KiB LDS-DMA pieces per row (the last one is 18 lanes wide: EXEC-masked)
+constexpr int kPitch = kRowB;              // LDS row pitch = the row itself (16-byte aligned): 148 KB in all, so that a fit
+                                           // workgroup (13 KB) of another stream can share the CU
 constexpr int kRing = 13;                  // rows in the window: 9 of the current step + 4 arriving for the next
-constexpr int kRingB = kRing * kPitch;     // 133 120
+constexpr int kRingB = kRing * kPitch;     // 123 552
 constexpr int kHRowB = 64 * 128;           // one horizontally pooled row: [64 pool px][64 ch] elements
-constexpr int kLds = kRingB + 3 * kHRowB;  // + A, B[2]  = 157 696
+constexpr int kLds = kRingB + 3 * kHRowB;  // + A, B[2]  = 148 128
 constexpr int kWBytes = 64 * 896 * 2;      // the weight matrix, 114 688 B = 112 LDS-DMA pieces
-constexpr int kWOff = 4 * kPitch;          // prologue: it passes through LDS behind ring rows 0..3 (ends at 155 648 < kLds)
-static_assert(kWOff + kWBytes <= kLds, "weight staging must fit behind the first four ring rows");
+constexpr int kWOff = 28 * 1024;           // prologue: it passes through LDS behind ring rows 0..2 (28 512 B), 1-KiB aligned
+static_assert(kWOff >= 3 * kPitch && kWOff + kWBytes <= kLds, "weight staging must fit behind the first three ring rows");
 
 // DPP row controls (a DPP row = 16 lanes = the 16 pixels of one MFMA tile)
 constexpr int kDppShl1 = 0x101;            // lane l <- lane l+1
@@ -110,17 +111,15 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
     const int first_row = 2 * (band * RB + 2 * s0);           // native input row of ring row 0
     const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * (262 * kRowB) + (size_t)first_row * kRowB;
 
-    // ---- LDS-DMA of one input row (relative index n) into its ring slot: 10 pieces, tail lanes re-read the last 16 bytes
+    // ---- LDS-DMA of one input row (relative index n) into its ring slot: 9 whole pieces + one of 18 lanes (288 bytes):
+    //      the slots are packed, a full tenth piece would run into the next slot's row
     const int lane_src = lane * 16;
     auto issue_row = [&](int n) {
         const unsigned char* src = in_b + (size_t)n * kRowB;
         unsigned char* dst = smem + (n % kRing) * kPitch;
 #pragma unroll
-        for (int p = 0; p < kRowPieces; ++p) {
-            int o = p * 1024 + lane_src;
-            o = o < kRowB - 16 ? o : kRowB - 16;
-            dma16(src + o, dst + p * 1024);
-        }
+        for (int p = 0; p < kRowPieces - 1; ++p) dma16(src + p * 1024 + lane_src, dst + p * 1024);
+        if (lane < (kRowB - (kRowPieces - 1) * 1024) / 16) dma16(src + (kRowPieces - 1) * 1024 + lane_src, dst + (kRowPieces - 1) * 1024);
     };
     const int frow = lane & 15, fq = lane >> 4;
     const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
@@ -129,8 +128,8 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
     // once).  Here the 114 KB matrix is ONE linear LDS-DMA copy (112 whole-line pieces) into the part of LDS the first four
     // input rows do not use, every wave then picks its 56 fragments with conflict-free ds_read_b128 (rows are 1792 B = 7 bank
     // rows apart, so the 16-byte chunk index is XORed with the row's low 4 bits -- on the DMA source, and on the read), and
-    // the remaining five rows of the first step are fetched behind it.
-    issue_row(wave);                                          // ring rows 0..3
+    // the remaining six rows of the first step are fetched behind it.
+    if (wave < 3) issue_row(wave);                            // ring rows 0..2
     {
         const unsigned char* const wb = reinterpret_cast<const unsigned char*>(a.w);
         for (int p = wave; p < kWBytes / 1024; p += 4) {
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                          // every wave has its fragments: the staging area is free
-    for (int n = 4 + wave; n < 9; n += 4) issue_row(n);       // ring rows 4..8
+    for (int n = 3 + wave; n < 9; n += 4) issue_row(n);       // ring rows 3..8
     // the row above the image is padding: the carry of the first step of the top band is all zeros (post-ReLU values are >= 0)
     if (s0 == 0)
         for (int i = tid; i < kHRowB / 16; i += 256) reinterpret_cast<uint4*>(hB + kHRowB)[i] = make_uint4(0u, 0u, 0u, 0u);

@@ -1,5 +1,6 @@
 // GPU driver of the reprojection fit: one 256-thread workgroup (4 wavefronts) per player, all iterations in one
-// launch, state in LDS (~29 KB), Adam moments in registers (one parameter per lane).  The arithmetic lives in fit_core.hpp (shared with the
+// launch, state in LDS (13 KB: the model constants a lane needs live in its registers, so a fit workgroup fits on a CU next to
+// a 148 KB convolution workgroup of another stream), Adam moments in registers (one parameter per lane).  The arithmetic lives in fit_core.hpp (shared with the
 // host emulation used by the CPU tests).  Latency-bound by design (10 workgroup barriers / iteration);
 // players are independent, so a batch fills one CU per player.
 #include <cmath>

@@ -90,7 +90,6 @@ struct alignas(16) FitShared {
     alignas(16) float part2[256];
     alignas(16) float dvp[16];
     alignas(16) float unit[4];         // (0, 0, 0, 1)
-    float fc[kFcTotal];
     float prm[232];          // [cam | R(24x9) | betas]; prm[229..231] unused
     float J[72];             // rest joints
     float Jrel[72];          // J_k - J_parent(k) (root: J_0)
@@ -151,7 +150,6 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
                       const int* level_joints, const int* level_start, const int* child_start,
                       const int* child_list, const float* R, const float* betas, const float* cam,
                       const float* joints2d, uint32_t param_mask) {
-    for (int i = lane; i < kFcTotal; i += kFitLanes) s.fc[i] = fitc[i];
     if (lane < 232) {
         const int p = lane;
         float v = 0.f;

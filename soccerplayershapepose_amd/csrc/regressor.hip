@@ -73,87 +73,123 @@ __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __rest
     out[idx] = Elem<F16>::one(v);
 }
 
-// ---- IEF fully-connected layer (fp32): out[b][n] = act(bias[n] + sum_k x[b][k] W[n][k]) (+ out, if accumulate)
-// The input row is the concatenation [x0[b][0:K0] | x1[b][0:K1]] (torch.cat([feat, params]), ief_module.py:55,59).
-// Workgroup = 4 waves = 4 neurons x 8 players: the 8 input rows are staged in LDS once (coalesced), each wave
-// loads the weight row of its neuron first (lanes stride over k; the L2 latency runs under the staging) and
-// reduces over lanes.  Latency-bound (9 dependent launches per forward); fp32 VALU keeps the regressor outputs
-// at reference precision downstream of the bf16 backbone.
-constexpr int kFcPB = 8, kFcNPW = 1, kFcNB = 4 * kFcNPW;
-template <int K0, int K1>
-__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                 const float* __restrict__ W, const float* __restrict__ bias, int N, int B,
-                                                 int relu, int accumulate, float* __restrict__ out, int out_stride) {
-    constexpr int K = K0 + K1, KI = (K + 63) / 64;
-    __shared__ float xs[kFcPB][K + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b0 = blockIdx.y * kFcPB;
-    // the weight rows of this wave's neurons first: their L2 latency runs under the staging of the input rows
-    float w[kFcNPW][KI];
-#pragma unroll
-    for (int q = 0; q < kFcNPW; ++q) {
-        const int n = min((int)blockIdx.x * kFcNB + wave * kFcNPW + q, N - 1);
-        const float* wr = W + (size_t)n * K;
-#pragma unroll
-        for (int i = 0; i < KI; ++i) { const int k = lane + 64 * i; w[q][i] = k < K ? wr[k] : 0.f; }
-    }
-    for (int i = threadIdx.x; i < kFcPB * K; i += 256) {
-        const int p = i / K, k = i - p * K;
-        const int b = min(b0 + p, B - 1);
-        xs[p][k] = k < K0 ? x0[(size_t)b * K0 + k] : x1[(size_t)b * K1 + (k - K0)];
+// ---- IEF (PR/models/ief_module.py:48-64) in ONE launch -------------------------------------------------------------
+// params = init;  3 x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) }:  nine dependent layers of 512 / 512 / 157
+// neurons on 32 players.  As nine launches (round 1) the layers cost ~10 us each in isolation and ~21 us plus a ~6 us gap
+// inside the 4-stream pipeline, where every launch queues behind other streams' chip-filling convolutions: ~250 us of a
+// stream's 1.4 ms chain, and shortening that chain is worth ~9 % of throughput (tools/chain_experiment.py).  Here 64
+// small workgroups per block of 32 players stay resident for the whole IEF and meet at a grid barrier after every layer:
+//   * thread = (player b, neuron j): 8 neurons of fc1 / fc2 per workgroup (512 / 64), 2-3 of fc3 (157 over 64);
+//   * fc1 is split: its 512 feature columns do not change over the iterations, so W1[:, :512] . feat + b1 is computed
+//     once and kept in a register; an iteration only adds W1[:, 512:] . params (K = 157, padded to 160);
+//   * activations cross workgroups through global memory (h1 / h2 / params, 64 KB at most, L2-resident); a workgroup
+//     needs ~0 LDS and ~64 VGPRs, so it fits on a CU beside a 148 KB / 432-register convolution workgroup;
+//   * the barrier is the placement-independent agent-scope form (guide, Guideline 16): every wave drains its stores,
+//     workgroup barrier, lane 0 releases (L2 write-back), adds to a monotonic counter (zeroed by a memset node before the
+//     launch), polls it relaxed with s_sleep, acquires (L1 invalidate), workgroup barrier, plain loads.  Spins are
+//     bounded; a time-out leaves NaNs in the outputs instead of hanging the GPU.
+constexpr int kIefG = 64;          // workgroups per block of 32 players
+constexpr int kParPitch = 160;     // params rows padded to a multiple of 4 floats
+
+struct IefArgs {
+    const float *feats, *w1f, *w1p, *b1, *w2, *b2, *w3, *b3, *init;
+    float *params, *h1, *h2;       // [B][160], [B][512], [B][512]: written and re-read across workgroups (never const/restrict)
+    float *cam, *pose, *betas;
+    unsigned int* counters;        // one monotonic arrival counter per block of 32 players
+    int B, iters;
+};
+
+__device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned int target) {
+    __shared__ int ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-back itself (hipcc may drop the fence's own wait)
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int spins = 0;
+        int good = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { good = 0; break; }        // ~ seconds: a workgroup never became resident
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok = good;
     }
     __syncthreads();
-    float acc[kFcNPW][kFcPB];
+    return ok != 0;
+}
+
+// sum_k w[k] x[k] over K floats (K % 4 == 0, both 16-byte aligned), 8 float4 pairs in flight
+template <int K>
+__device__ __forceinline__ float ief_dot(const float* w, const float* x, float acc) {
+    static_assert(K % 32 == 0, "unrolled by 8 float4");
+#pragma unroll 1
+    for (int k = 0; k < K; k += 32) {
+        float4 wv[8], xv[8];
 #pragma unroll
-    for (int q = 0; q < kFcNPW; ++q)
+        for (int u = 0; u < 8; ++u) { wv[u] = *reinterpret_cast<const float4*>(w + k + 4 * u); xv[u] = *reinterpret_cast<const float4*>(x + k + 4 * u); }
 #pragma unroll
-        for (int p = 0; p < kFcPB; ++p) acc[q][p] = 0.f;
-#pragma unroll
-    for (int i = 0; i < KI; ++i) {
-        const int k = min(lane + 64 * i, K - 1);
-#pragma unroll
-        for (int p = 0; p < kFcPB; ++p) {
-            const float xv = xs[p][k];
-#pragma unroll
-            for (int q = 0; q < kFcNPW; ++q) acc[q][p] = fmaf(w[q][i], xv, acc[q][p]);
+        for (int u = 0; u < 8; ++u) {
+            acc = fmaf(wv[u].x, xv[u].x, acc); acc = fmaf(wv[u].y, xv[u].y, acc);
+            acc = fmaf(wv[u].z, xv[u].z, acc); acc = fmaf(wv[u].w, xv[u].w, acc);
         }
     }
-#pragma unroll
-    for (int q = 0; q < kFcNPW; ++q) {
-        const int n = blockIdx.x * kFcNB + wave * kFcNPW + q;
-#pragma unroll
-        for (int p = 0; p < kFcPB; ++p) {
-            float v = acc[q][p];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            acc[q][p] = v;
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
+    const int t = threadIdx.x, g = blockIdx.x, pb = blockIdx.y;
+    const int b = pb * 32 + (t & 31), j = t >> 5;
+    const bool live = b < a.B;
+    const int bb = live ? b : a.B - 1;                       // idle lanes recompute the last player (no stores)
+    const int n12 = g * 8 + j;                               // this thread's neuron in fc1 / fc2
+    const int m3 = g + kIefG * j;                            // ... and in fc3 (j < 3, m3 < 157)
+    unsigned int* const counter = a.counters + pb;
+    unsigned int phase = 0;
+    // fc1, constant part
+    const float f1 = ief_dot<kFeat>(a.w1f + (size_t)n12 * kFeat, a.feats + (size_t)bb * kFeat, a.b1[n12]);
+    // params = init (this block's 32 rows, spread over its 64 workgroups)
+    {
+        const int idx = g * 256 + t;
+        if (idx < 32 * kParPitch) {
+            const int row = pb * 32 + idx / kParPitch, col = idx % kParPitch;
+            if (row < a.B) a.params[(size_t)row * kParPitch + col] = col < kNPar ? a.init[col] : 0.f;
         }
-        if (n < N && lane < kFcPB && b0 + lane < B) {
-            float v = 0.f;
-#pragma unroll
-            for (int p = 0; p < kFcPB; ++p) v = (lane == p) ? acc[q][p] : v;
-            v += bias[n];
-            if (relu) v = fmaxf(v, 0.f);
-            float* o = out + (size_t)(b0 + lane) * out_stride + n;
-            *o = accumulate ? (*o + v) : v;
+    }
+    bool ok = ief_grid_barrier(counter, kIefG * ++phase);
+    for (int it = 0; it < a.iters; ++it) {
+        float v = ief_dot<kParPitch>(a.w1p + (size_t)n12 * kParPitch, a.params + (size_t)bb * kParPitch, f1);
+        if (live) a.h1[(size_t)b * kHid + n12] = fmaxf(v, 0.f);
+        ok &= ief_grid_barrier(counter, kIefG * ++phase);
+        v = ief_dot<kHid>(a.w2 + (size_t)n12 * kHid, a.h1 + (size_t)bb * kHid, a.b2[n12]);
+        if (live) a.h2[(size_t)b * kHid + n12] = fmaxf(v, 0.f);
+        ok &= ief_grid_barrier(counter, kIefG * ++phase);
+        if (j < 3 && m3 < kNPar) {
+            v = ief_dot<kHid>(a.w3 + (size_t)m3 * kHid, a.h2 + (size_t)bb * kHid, a.b3[m3]);
+            float p = a.params[(size_t)bb * kParPitch + m3] + v;
+            if (!ok) p = __builtin_nanf("");
+            if (live) {
+                if (it + 1 < a.iters) a.params[(size_t)b * kParPitch + m3] = p;
+                else if (m3 < 3) a.cam[b * 3 + m3] = p;
+                else if (m3 < 147) a.pose[(size_t)b * 144 + (m3 - 3)] = p;
+                else a.betas[b * 10 + (m3 - 147)] = p;
+            }
         }
+        if (it + 1 < a.iters) ok &= ief_grid_barrier(counter, kIefG * ++phase);
     }
 }
 
-__global__ void init_params_kernel(const float* __restrict__ init, int B, float* __restrict__ params) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B * kNPar) params[i] = init[i % kNPar];
-}
-
-__global__ void split_params_kernel(const float* __restrict__ params, int B, float* __restrict__ cam,
-                                    float* __restrict__ pose, float* __restrict__ betas) {
+// IEF with no iterations (never used by the reference): outputs = the initial estimate
+__global__ void ief_init_only_kernel(const float* __restrict__ init, int B, float* __restrict__ cam, float* __restrict__ pose, float* __restrict__ betas) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * kNPar) return;
-    const int b = i / kNPar, j = i % kNPar;
-    const float v = params[i];
-    if (j < 3) cam[b * 3 + j] = v;
-    else if (j < 147) pose[b * 144 + (j - 3)] = v;
-    else betas[b * 10 + (j - 147)] = v;
+    const int b = i / kNPar, jj = i % kNPar;
+    const float v = init[jj];
+    if (jj < 3) cam[b * 3 + jj] = v;
+    else if (jj < 147) pose[b * 144 + (jj - 3)] = v;
+    else betas[b * 10 + (jj - 147)] = v;
 }
 
 }  // namespace
@@ -165,7 +201,7 @@ struct spsp_regressor {
     int f16;               // 0: bf16 storage + bf16 MFMA (precision 0), 1: fp16 storage + f16 MFMA (precision 1)
     uint16_t* w[SPSP_NUM_CONVS];
     float* bias[SPSP_NUM_CONVS];
-    float* fcw[3];
+    float *w1f, *w1p, *w2, *w3;   // fc1 split into its feature columns [512][512] and its params columns [512][160]; fc2; fc3
     float* fcb[3];
     float* init_params;
     // feature maps (bf16, zero border)
@@ -275,10 +311,19 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         TRY(r->pool.upload(&r->w[ci], wt.data(), wt.size()));
         TRY(r->pool.upload(&r->bias[ci], bias.data(), bias.size()));
     }
-    const int fcn[3] = {kHid, kHid, kNPar}, fck[3] = {kFeat + kNPar, kHid, kHid};
-    for (int i = 0; i < 3; ++i) {
-        TRY(r->pool.upload(&r->fcw[i], w->fc_weight[i], (size_t)fcn[i] * fck[i]));
-        TRY(r->pool.upload(&r->fcb[i], w->fc_bias[i], (size_t)fcn[i]));
+    {   // fc1 [512][669] split by columns (ief_module.py:55 concatenates [feat | params]); fc2 / fc3 as they are
+        std::vector<float> w1f((size_t)kHid * kFeat), w1p((size_t)kHid * kParPitch, 0.f);
+        for (int n = 0; n < kHid; ++n) {
+            const float* row = w->fc_weight[0] + (size_t)n * (kFeat + kNPar);
+            std::memcpy(&w1f[(size_t)n * kFeat], row, kFeat * sizeof(float));
+            std::memcpy(&w1p[(size_t)n * kParPitch], row + kFeat, kNPar * sizeof(float));
+        }
+        TRY(r->pool.upload(&r->w1f, w1f.data(), w1f.size()));
+        TRY(r->pool.upload(&r->w1p, w1p.data(), w1p.size()));
+        TRY(r->pool.upload(&r->w2, w->fc_weight[1], (size_t)kHid * kHid));
+        TRY(r->pool.upload(&r->w3, w->fc_weight[2], (size_t)kNPar * kHid));
+        const int fcn[3] = {kHid, kHid, kNPar};
+        for (int i = 0; i < 3; ++i) TRY(r->pool.upload(&r->fcb[i], w->fc_bias[i], (size_t)fcn[i]));
     }
     TRY(r->pool.upload(&r->init_params, w->init_params, (size_t)kNPar));
     const size_t B = max_batch;
@@ -297,7 +342,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; }
     }
     TRY(r->pool.alloc(&r->feats, B * kFeat));
-    TRY(r->pool.alloc(&r->params, B * kNPar));
+    TRY(r->pool.alloc(&r->params, B * kParPitch));
     TRY(r->pool.alloc(&r->h1, B * kHid));
     TRY(r->pool.alloc(&r->h2, B * kHid));
 #undef TRY
@@ -377,25 +422,21 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         r->stage_ptr[2 + L] = x;
     }
     r->last_B = B;
-    // IEF (ief_module.py:48-64): params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) }
-    {
+    // IEF (ief_module.py:48-64): params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) } -- one launch
+    if (r->ief_iters > 0) {
+        const int npb = (B + 31) / 32;
+        SPSP_REQUIRE(npb <= 8, "spsp_regressor_forward: the fused IEF holds at most 256 players per call");
+        IefArgs ia;
+        ia.feats = r->feats; ia.w1f = r->w1f; ia.w1p = r->w1p; ia.b1 = r->fcb[0]; ia.w2 = r->w2; ia.b2 = r->fcb[1];
+        ia.w3 = r->w3; ia.b3 = r->fcb[2]; ia.init = r->init_params;
+        ia.params = r->params; ia.h1 = r->h1; ia.h2 = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
+        ia.counters = r->counters + 8;           // words 8..15 of the per-forward counter block (zeroed above)
+        ia.B = B; ia.iters = r->ief_iters;
+        ProfScope ps(ctx, kKIefFc, st);
+        ief_fused_kernel<<<dim3(kIefG, npb), 256, 0, st>>>(ia);
+    } else {
         ProfScope ps(ctx, kKIefMisc, st);
-        init_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, r->params);
-    }
-    SPSP_HIP_CHECK(hipGetLastError());
-    const dim3 gh((kHid + kFcNB - 1) / kFcNB, (B + kFcPB - 1) / kFcPB), go((kNPar + kFcNB - 1) / kFcNB, (B + kFcPB - 1) / kFcPB);
-    for (int it = 0; it < r->ief_iters; ++it) {
-        { ProfScope ps(ctx, kKIefFc, st);
-          fc_kernel<kFeat, kNPar><<<gh, 256, 0, st>>>(r->feats, r->params, r->fcw[0], r->fcb[0], kHid, B, 1, 0, r->h1, kHid); }
-        { ProfScope ps(ctx, kKIefFc, st);
-          fc_kernel<kHid, 0><<<gh, 256, 0, st>>>(r->h1, nullptr, r->fcw[1], r->fcb[1], kHid, B, 1, 0, r->h2, kHid); }
-        { ProfScope ps(ctx, kKIefFc, st);
-          fc_kernel<kHid, 0><<<go, 256, 0, st>>>(r->h2, nullptr, r->fcw[2], r->fcb[2], kNPar, B, 0, 1, r->params, kNPar); }
-        SPSP_HIP_CHECK(hipGetLastError());
-    }
-    {
-        ProfScope ps(ctx, kKIefMisc, st);
-        split_params_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->params, B, cam, pose6d, betas);
+        ief_init_only_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, cam, pose6d, betas);
     }
     SPSP_HIP_CHECK(hipGetLastError());
     if (feats) SPSP_HIP_CHECK(hipMemcpyAsync(feats, r->feats, (size_t)B * kFeat * sizeof(float), hipMemcpyDeviceToDevice, st));
