@@ -74,28 +74,41 @@ __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __rest
 }
 
 // ---- IEF (PR/models/ief_module.py:48-64) in ONE launch -------------------------------------------------------------
-// params = init;  3 x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) }:  nine dependent layers of 512 / 512 / 157
-// neurons on 32 players.  As nine launches (round 1) the layers cost ~10 us each in isolation and ~21 us plus a ~6 us gap
-// inside the 4-stream pipeline, where every launch queues behind other streams' chip-filling convolutions: ~250 us of a
-// stream's 1.4 ms chain, and shortening that chain is worth ~9 % of throughput (tools/chain_experiment.py).  Here 64
-// small workgroups per block of 32 players stay resident for the whole IEF and meet at a grid barrier after every layer:
-//   * thread = (player b, neuron j): 8 neurons of fc1 / fc2 per workgroup (512 / 64), 2-3 of fc3 (157 over 64);
-//   * fc1 is split: its 512 feature columns do not change over the iterations, so W1[:, :512] . feat + b1 is computed
-//     once and kept in a register; an iteration only adds W1[:, 512:] . params (K = 157, padded to 160);
-//   * activations cross workgroups through global memory (h1 / h2 / params, 64 KB at most, L2-resident); a workgroup
-//     needs ~0 LDS and ~64 VGPRs, so it fits on a CU beside a 148 KB / 432-register convolution workgroup;
-//   * the barrier is the placement-independent agent-scope form (guide, Guideline 16): every wave drains its stores,
-//     workgroup barrier, lane 0 releases (L2 write-back), adds to a monotonic counter (zeroed by a memset node before the
-//     launch), polls it relaxed with s_sleep, acquires (L1 invalidate), workgroup barrier, plain loads.  Spins are
-//     bounded; a time-out leaves NaNs in the outputs instead of hanging the GPU.
+// params_0 = init;  params_{i+1} = params_i + fc3(relu(fc2(relu(fc1([feat | params_i])))))  for i < 3:  nine dependent
+// layers of 512 / 512 / 157 neurons on 32 players.  As nine launches (round 1) the layers cost ~10 us each in isolation
+// and ~21 us plus a ~6 us gap inside the 4-stream pipeline, where every launch queues behind other streams' chip-filling
+// convolutions: ~250 us of a stream's 1.4 ms chain (tools/chain_experiment.py: removing them is worth 9 % of throughput).
+//
+// Algebra first (exact in real arithmetic; the fp32 reassociation is ~1e-6, the parity tolerance 2e-5).  With
+// W1 = [W1f | W1p] split by input columns and S_i = h2_0 + ... + h2_{i-1}:
+//     params_i = init + i*b3 + W3 S_i
+//     h1_i     = relu(W1f feat + c_i + W13 S_i),   c_i = b1 + W1p (init + i*b3),   W13 = W1p W3   (host, fp64 -> fp32)
+//     h2_i     = relu(b2 + W2 h1_i)
+//     result   = init + 3*b3 + W3 S_3
+// so the 157-wide params vector never has to exist between layers: fc3 of one iteration and fc1 of the next collapse
+// into ONE 512x512 product, the feature product W1f feat is done once, and h1_0 needs no product at all.  Seven K=512
+// products and six grid-wide hand-offs instead of nine products of K = 669 / 512 / 512 and ten hand-offs.
+//
+// Mapping: 64 workgroups per block of 32 players stay resident for the whole IEF; workgroup g owns neurons 8g..8g+7 of
+// every 512-wide layer (and of fc3 while 8g < 157), whose four 16 KB weight slices it loads into LDS once.  A thread is
+// (player pair, k-slice s of 16): it holds its two players' x[k], k = 4*(16u+s)..+3, in registers (coalesced float4
+// loads straight from L2 -- the activations are 64 KB and written by other workgroups), reads each neuron's weights as
+// broadcast ds_read_b128 (16 lanes x 16 B contiguous: conflict-free), and the 16 k-slices of a DPP row are summed with
+// four row operations.  Lane s of a row then owns output (neuron s&7, player s>>3) for the whole kernel: W1f feat and
+// the running sum S live in its registers.
+// Hand-off between layers = the placement-independent agent-scope barrier of the guide (Guideline 16): every wave drains
+// its stores, workgroup barrier, lane 0 releases (L2 write-back), adds to a monotonic counter (zeroed by a memset node
+// before the launch), polls it relaxed with s_sleep, acquires (L1 invalidate), workgroup barrier, plain loads.  Spins
+// are bounded; a time-out leaves NaNs in the outputs instead of hanging the GPU.
 constexpr int kIefG = 64;          // workgroups per block of 32 players
-constexpr int kParPitch = 160;     // params rows padded to a multiple of 4 floats
+constexpr int kIefLds = 4 * 8 * 512 * 4;   // four [8][512] fp32 weight slices
 
 struct IefArgs {
-    const float *feats, *w1f, *w1p, *b1, *w2, *b2, *w3, *b3, *init;
-    float *params, *h1, *h2;       // [B][160], [B][512], [B][512]: written and re-read across workgroups (never const/restrict)
+    const float *feats, *w1f, *w13, *w2, *w3;   // [512][512] x3, [157][512]
+    const float *cvec, *b2, *p0;                // c_i [iters][512], b2 [512], init + iters*b3 [157]
+    float *h1, *s;                              // [B][512] each: written and re-read across workgroups (never const/restrict)
     float *cam, *pose, *betas;
-    unsigned int* counters;        // one monotonic arrival counter per block of 32 players
+    unsigned int* counters;                     // one monotonic arrival counter per block of 32 players
     int B, iters;
 };
 
@@ -110,7 +123,7 @@ __device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned
         unsigned int spins = 0;
         int good = 1;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 22)) { good = 0; break; }        // ~ seconds: a workgroup never became resident
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -121,63 +134,92 @@ __device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned
     return ok != 0;
 }
 
-// sum_k w[k] x[k] over K floats (K % 4 == 0, both 16-byte aligned), 8 float4 pairs in flight
-template <int K>
-__device__ __forceinline__ float ief_dot(const float* w, const float* x, float acc) {
-    static_assert(K % 32 == 0, "unrolled by 8 float4");
-#pragma unroll 1
-    for (int k = 0; k < K; k += 32) {
-        float4 wv[8], xv[8];
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float ief_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// One 8-neuron x 2-player product over K = 512: x rows from global memory, the weight slice from LDS.  Returns, in lane s
+// of each row, the dot product for (neuron s & 7, player s >> 3).
+__device__ __forceinline__ float ief_product(const float* wl, const float* x0, const float* x1, int s) {
+    float4 xa[8], xb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { wv[u] = *reinterpret_cast<const float4*>(w + k + 4 * u); xv[u] = *reinterpret_cast<const float4*>(x + k + 4 * u); }
+    for (int u = 0; u < 8; ++u) {
+        xa[u] = *reinterpret_cast<const float4*>(x0 + 4 * (16 * u + s));
+        xb[u] = *reinterpret_cast<const float4*>(x1 + 4 * (16 * u + s));
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            acc = fmaf(wv[u].x, xv[u].x, acc); acc = fmaf(wv[u].y, xv[u].y, acc);
-            acc = fmaf(wv[u].z, xv[u].z, acc); acc = fmaf(wv[u].w, xv[u].w, acc);
+            const float4 w = *reinterpret_cast<const float4*>(wl + n * 512 + 4 * (16 * u + s));
+            a0 = fmaf(w.x, xa[u].x, a0); a0 = fmaf(w.y, xa[u].y, a0); a0 = fmaf(w.z, xa[u].z, a0); a0 = fmaf(w.w, xa[u].w, a0);
+            a1 = fmaf(w.x, xb[u].x, a1); a1 = fmaf(w.y, xb[u].y, a1); a1 = fmaf(w.z, xb[u].z, a1); a1 = fmaf(w.w, xb[u].w, a1);
         }
+        a0 = ief_row_sum(a0);
+        a1 = ief_row_sum(a1);
+        mine = s == n ? a0 : (s == n + 8 ? a1 : mine);
     }
-    return acc;
+    return mine;
 }
 
 __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
+    extern __shared__ __align__(16) float ief_w[];           // [4][8][512]: W1f, W13, W2, W3 rows 8g..8g+7
     const int t = threadIdx.x, g = blockIdx.x, pb = blockIdx.y;
-    const int b = pb * 32 + (t & 31), j = t >> 5;
+    const int s = t & 15, pair = t >> 4;                     // k-slice, player pair of this block of 32
+    const int bA = pb * 32 + 2 * pair, bB = bA + 1;
+    const int n = 8 * g + (s & 7);                           // the neuron this lane owns ...
+    const int b = (s >> 3) ? bB : bA;                        // ... for this player
     const bool live = b < a.B;
-    const int bb = live ? b : a.B - 1;                       // idle lanes recompute the last player (no stores)
-    const int n12 = g * 8 + j;                               // this thread's neuron in fc1 / fc2
-    const int m3 = g + kIefG * j;                            // ... and in fc3 (j < 3, m3 < 157)
+    const int rA = bA < a.B ? bA : a.B - 1, rB = bB < a.B ? bB : a.B - 1;   // idle lanes recompute the last player (no stores)
     unsigned int* const counter = a.counters + pb;
     unsigned int phase = 0;
-    // fc1, constant part
-    const float f1 = ief_dot<kFeat>(a.w1f + (size_t)n12 * kFeat, a.feats + (size_t)bb * kFeat, a.b1[n12]);
-    // params = init (this block's 32 rows, spread over its 64 workgroups)
-    {
-        const int idx = g * 256 + t;
-        if (idx < 32 * kParPitch) {
-            const int row = pb * 32 + idx / kParPitch, col = idx % kParPitch;
-            if (row < a.B) a.params[(size_t)row * kParPitch + col] = col < kNPar ? a.init[col] : 0.f;
-        }
-    }
-    bool ok = ief_grid_barrier(counter, kIefG * ++phase);
-    for (int it = 0; it < a.iters; ++it) {
-        float v = ief_dot<kParPitch>(a.w1p + (size_t)n12 * kParPitch, a.params + (size_t)bb * kParPitch, f1);
-        if (live) a.h1[(size_t)b * kHid + n12] = fmaxf(v, 0.f);
-        ok &= ief_grid_barrier(counter, kIefG * ++phase);
-        v = ief_dot<kHid>(a.w2 + (size_t)n12 * kHid, a.h1 + (size_t)bb * kHid, a.b2[n12]);
-        if (live) a.h2[(size_t)b * kHid + n12] = fmaxf(v, 0.f);
-        ok &= ief_grid_barrier(counter, kIefG * ++phase);
-        if (j < 3 && m3 < kNPar) {
-            v = ief_dot<kHid>(a.w3 + (size_t)m3 * kHid, a.h2 + (size_t)bb * kHid, a.b3[m3]);
-            float p = a.params[(size_t)bb * kParPitch + m3] + v;
-            if (!ok) p = __builtin_nanf("");
-            if (live) {
-                if (it + 1 < a.iters) a.params[(size_t)b * kParPitch + m3] = p;
-                else if (m3 < 3) a.cam[b * 3 + m3] = p;
-                else if (m3 < 147) a.pose[(size_t)b * 144 + (m3 - 3)] = p;
-                else a.betas[b * 10 + (m3 - 147)] = p;
+
+    {   // weight slices -> LDS (rows 8g.. of each matrix are 16 KB contiguous; fc3 has 157 rows)
+        const float* src[4] = {a.w1f, a.w13, a.w2, a.w3};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = 4 * (t + 256 * q);             // float index in the [8][512] slice
+                const int row = 8 * g + e / 512;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < 3 || row < kNPar) v = *reinterpret_cast<const float4*>(src[m] + (size_t)row * 512 + e % 512);
+                *reinterpret_cast<float4*>(ief_w + m * 4096 + e) = v;
             }
+    }
+    __syncthreads();
+
+    const float f1 = ief_product(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s);
+    if (live) a.h1[(size_t)b * kHid + n] = fmaxf(f1 + a.cvec[n], 0.f);
+    bool ok = ief_grid_barrier(counter, kIefG * ++phase);
+    float ssum = 0.f;
+    const float b2 = a.b2[n];
+    for (int it = 0; it < a.iters; ++it) {
+        if (it > 0) {
+            const float v = ief_product(ief_w + 4096, a.s + (size_t)rA * kHid, a.s + (size_t)rB * kHid, s);
+            if (live) a.h1[(size_t)b * kHid + n] = fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f);
+            ok &= ief_grid_barrier(counter, kIefG * ++phase);
         }
-        if (it + 1 < a.iters) ok &= ief_grid_barrier(counter, kIefG * ++phase);
+        const float v = ief_product(ief_w + 2 * 4096, a.h1 + (size_t)rA * kHid, a.h1 + (size_t)rB * kHid, s);
+        ssum += fmaxf(b2 + v, 0.f);
+        if (live) a.s[(size_t)b * kHid + n] = ssum;
+        ok &= ief_grid_barrier(counter, kIefG * ++phase);
+    }
+    if (8 * g < kNPar) {
+        float v = a.p0[n < kNPar ? n : 0] + ief_product(ief_w + 3 * 4096, a.s + (size_t)rA * kHid, a.s + (size_t)rB * kHid, s);
+        if (!ok) v = __builtin_nanf("");
+        if (live && n < kNPar) {
+            if (n < 3) a.cam[b * 3 + n] = v;
+            else if (n < 147) a.pose[(size_t)b * 144 + (n - 3)] = v;
+            else a.betas[b * 10 + (n - 147)] = v;
+        }
     }
 }
 
@@ -201,14 +243,14 @@ struct spsp_regressor {
     int f16;               // 0: bf16 storage + bf16 MFMA (precision 0), 1: fp16 storage + f16 MFMA (precision 1)
     uint16_t* w[SPSP_NUM_CONVS];
     float* bias[SPSP_NUM_CONVS];
-    float *w1f, *w1p, *w2, *w3;   // fc1 split into its feature columns [512][512] and its params columns [512][160]; fc2; fc3
-    float* fcb[3];
+    float *w1f, *w13, *w2, *w3;   // IEF weights in the fused kernel's form (see ief_fused_kernel)
+    float *cvec, *b2, *p0;
     float* init_params;
     // feature maps (bf16, zero border)
     uint16_t* x0;          // [B][262][262][18]
     uint16_t* p1;          // [B][66][66][64] max-pool output
     uint16_t* l[4][3];     // layer L: [B][S+2][S+2][C], S = 64,32,16,8; C = 64,128,256,512
-    float *feats, *params, *h1, *h2;
+    float *feats, *h1, *h2;
     const uint16_t* stage_ptr[6];
     int last_B;
     unsigned int* counters;  // tile-scheduler words of the persistent kernels (zeroed at the start of every forward)
@@ -311,19 +353,35 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         TRY(r->pool.upload(&r->w[ci], wt.data(), wt.size()));
         TRY(r->pool.upload(&r->bias[ci], bias.data(), bias.size()));
     }
-    {   // fc1 [512][669] split by columns (ief_module.py:55 concatenates [feat | params]); fc2 / fc3 as they are
-        std::vector<float> w1f((size_t)kHid * kFeat), w1p((size_t)kHid * kParPitch, 0.f);
+    {   // fc1 [512][669] split by input columns (ief_module.py:55 concatenates [feat | params]); products in fp64
+        const int it_n = w->ief_iters > 0 ? w->ief_iters : 1;
+        std::vector<float> w1f((size_t)kHid * kFeat), w13((size_t)kHid * kHid), cvec((size_t)it_n * kHid), p0(kNPar);
+        std::vector<double> acc(kHid);
+        const float *W1 = w->fc_weight[0], *W3 = w->fc_weight[2], *b1 = w->fc_bias[0], *b3 = w->fc_bias[2];
         for (int n = 0; n < kHid; ++n) {
-            const float* row = w->fc_weight[0] + (size_t)n * (kFeat + kNPar);
+            const float* row = W1 + (size_t)n * (kFeat + kNPar);
             std::memcpy(&w1f[(size_t)n * kFeat], row, kFeat * sizeof(float));
-            std::memcpy(&w1p[(size_t)n * kParPitch], row + kFeat, kNPar * sizeof(float));
+            std::fill(acc.begin(), acc.end(), 0.0);
+            for (int p = 0; p < kNPar; ++p) {
+                const double wp = row[kFeat + p];
+                const float* w3row = W3 + (size_t)p * kHid;
+                for (int k = 0; k < kHid; ++k) acc[k] += wp * (double)w3row[k];
+            }
+            for (int k = 0; k < kHid; ++k) w13[(size_t)n * kHid + k] = (float)acc[k];
+            for (int it = 0; it < it_n; ++it) {
+                double c = b1[n];
+                for (int p = 0; p < kNPar; ++p) c += (double)row[kFeat + p] * ((double)w->init_params[p] + (double)it * (double)b3[p]);
+                cvec[(size_t)it * kHid + n] = (float)c;
+            }
         }
+        for (int p = 0; p < kNPar; ++p) p0[p] = (float)((double)w->init_params[p] + (double)w->ief_iters * (double)b3[p]);
         TRY(r->pool.upload(&r->w1f, w1f.data(), w1f.size()));
-        TRY(r->pool.upload(&r->w1p, w1p.data(), w1p.size()));
+        TRY(r->pool.upload(&r->w13, w13.data(), w13.size()));
         TRY(r->pool.upload(&r->w2, w->fc_weight[1], (size_t)kHid * kHid));
-        TRY(r->pool.upload(&r->w3, w->fc_weight[2], (size_t)kNPar * kHid));
-        const int fcn[3] = {kHid, kHid, kNPar};
-        for (int i = 0; i < 3; ++i) TRY(r->pool.upload(&r->fcb[i], w->fc_bias[i], (size_t)fcn[i]));
+        TRY(r->pool.upload(&r->w3, W3, (size_t)kNPar * kHid));
+        TRY(r->pool.upload(&r->cvec, cvec.data(), cvec.size()));
+        TRY(r->pool.upload(&r->b2, w->fc_bias[1], (size_t)kHid));
+        TRY(r->pool.upload(&r->p0, p0.data(), p0.size()));
     }
     TRY(r->pool.upload(&r->init_params, w->init_params, (size_t)kNPar));
     const size_t B = max_batch;
@@ -342,7 +400,6 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; }
     }
     TRY(r->pool.alloc(&r->feats, B * kFeat));
-    TRY(r->pool.alloc(&r->params, B * kParPitch));
     TRY(r->pool.alloc(&r->h1, B * kHid));
     TRY(r->pool.alloc(&r->h2, B * kHid));
 #undef TRY
@@ -427,13 +484,14 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         const int npb = (B + 31) / 32;
         SPSP_REQUIRE(npb <= 8, "spsp_regressor_forward: the fused IEF holds at most 256 players per call");
         IefArgs ia;
-        ia.feats = r->feats; ia.w1f = r->w1f; ia.w1p = r->w1p; ia.b1 = r->fcb[0]; ia.w2 = r->w2; ia.b2 = r->fcb[1];
-        ia.w3 = r->w3; ia.b3 = r->fcb[2]; ia.init = r->init_params;
-        ia.params = r->params; ia.h1 = r->h1; ia.h2 = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
+        ia.feats = r->feats; ia.w1f = r->w1f; ia.w13 = r->w13; ia.w2 = r->w2; ia.w3 = r->w3;
+        ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
+        ia.h1 = r->h1; ia.s = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
         ia.counters = r->counters + 8;           // words 8..15 of the per-forward counter block (zeroed above)
         ia.B = B; ia.iters = r->ief_iters;
+        SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel>(kIefLds));
         ProfScope ps(ctx, kKIefFc, st);
-        ief_fused_kernel<<<dim3(kIefG, npb), 256, 0, st>>>(ia);
+        ief_fused_kernel<<<dim3(kIefG, npb), 256, kIefLds, st>>>(ia);
     } else {
         ProfScope ps(ctx, kKIefMisc, st);
         ief_init_only_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, cam, pose6d, betas);
