@@ -1,15 +1,26 @@
 // 3x3 / stride-1 convolution, 64 -> 64 channels (ResNet-18 layer1: 4 convs, 12 % of the FLOPs but the largest share of
-// GPU time of the patch kernels) with the WHOLE WEIGHT TENSOR RESIDENT IN LDS.
+// GPU time of the 3x3 kernels) with the WHOLE WEIGHT TENSOR RESIDENT IN LDS.
 //
 // conv_patch.hip streams one [64 x 64] weight slab per filter tap through an LDS-DMA ring and therefore pays a
-// counted-vmcnt wait + workgroup barrier per tap (measured ~600 cycles of overhead next to 512 cycles of MFMA).  With
-// Cin = Cout = 64 all nine slabs are 73.7 KB: this kernel loads them ONCE per workgroup, makes the workgroups
-// persistent over the 16 x 16-pixel tiles, and runs the 9 taps x 32 MFMAs of a tile back to back with no barrier at
-// all; fragment reads are software-pipelined one tap ahead (two register sets), the next tile's input patch is
-// fetched by LDS-DMA while the current tile's epilogue runs.
+// counted-vmcnt wait + workgroup barrier per tap.  With Cin = Cout = 64 all nine slabs are 73.7 KB: this kernel loads
+// them ONCE per workgroup, makes the workgroups persistent over the 16 x 16-pixel tiles, and runs the 9 taps x 32 MFMAs
+// of a tile back to back with no barrier at all; fragment reads are software-pipelined one tap ahead (two register sets).
 //
-// Workgroup = 4 waves (one per SIMD), wave tile 64 px x 64 ch on v_mfma_f32_16x16x32_bf16 (weights = A operand,
-// pixels = B operand).  LDS: weights 73.7 KB + patch 41 KB + epilogue staging 32 KB = 147 KB.
+// Round 2: the phases of consecutive tiles overlap.  At 64 channels a tile moves 32 KB in, 32 KB out and 32 KB of
+// residual for 4.6k cycles of MFMA, and the first version ran load -> K loop -> epilogue one after the other (stamps:
+// K loop 5.4k of ~13k cycles per tile).  Now
+//   * TWO patch buffers: the next tile's input patch is fetched by LDS-DMA under the current tile's K loop;
+//   * the epilogue needs no LDS and no barrier: the weight rows are permuted at load time so that, after the MFMAs, a lane
+//     holds 2 x 8 CONSECUTIVE output channels of each of its pixels (accumulator tile i, register e of lane group fq is
+//     channel 32 (i >> 1) + 8 fq + 4 (i & 1) + e) -- residual loads and output stores are plain 16-byte accesses, four
+//     lanes covering an aligned 64-byte half line;
+//   * the previous tile's accumulators stay in registers (two accumulator sets, the tile loop is unrolled by two) and its
+//     bias + residual + ReLU + pack + store is issued in eight pieces between the MFMAs of the current tile's taps; the
+//     current tile's residual is loaded into the registers those pieces free.
+// One s_waitcnt vmcnt(0) + one workgroup barrier per tile remain (patch landed / every wave has left the other buffer).
+//
+// Workgroup = 4 waves (one per SIMD), wave tile 64 px x 64 ch on v_mfma_f32_16x16x32 (weights = A operand, pixels = B
+// operand).  LDS: weights 73.7 KB + 2 x patch 41 KB = 155.7 KB.
 #include <cstdlib>
 #include <type_traits>
 
@@ -39,8 +50,8 @@ constexpr int kWSlab = 64 * 128;                 // one tap: [64 n][64 k] bf16
 constexpr int kWAll = 9 * kWSlab;                // 73 728 B
 constexpr int kNPix = 324, kNDma = 41;           // 18 x 18 patch, 8 pixels per 1-KiB DMA piece
 constexpr int kPatch = kNDma * 1024;             // 41 984 B
-constexpr int kStage = 256 * 128;                // epilogue staging tile [256 px][128 B]
-constexpr int kLds = kWAll + kPatch + kStage + 16; // 148 496 B (last 16 B: tile-id broadcast slot)
+constexpr int kBiasOff = kWAll + 2 * kPatch;     // 64 fp32 biases in accumulator order (row R of the permuted weights)
+constexpr int kLds = kBiasOff + 256 + 16;        // 157 968 B (last 16 B: tile-id slots)
 
 #ifdef SPSP_CONV_STAMPS
 #define WSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
@@ -48,13 +59,15 @@ constexpr int kLds = kWAll + kPatch + kStage + 16; // 148 496 B (last 16 B: tile
 #define WSTAMP(i)
 #endif
 
-template <bool F16>
+// output channel held by accumulator tile i, MFMA row r (= 4 fq + e) -- see the header
+__host__ __device__ constexpr int wres_channel(int i, int r) { return 32 * (i >> 1) + 8 * (r >> 2) + 4 * (i & 1) + (r & 3); }
+
+template <bool F16, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const wlds = smem;
-    unsigned char* const patch = smem + kWAll;
-    unsigned char* const stage = smem + kWAll + kPatch;
-    volatile int* const s_tile = reinterpret_cast<volatile int*>(smem + kWAll + kPatch + kStage);
+    unsigned char* const patch = smem + kWAll;               // two buffers of kPatch
+    volatile int* const s_tile = reinterpret_cast<volatile int*>(smem + kBiasOff + 256);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,21 +75,31 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     const int ntiles = a.M / 256;
     const uint16_t* const in_ptr = a.in;
 
-    // first tile id (dynamic scheduler, see below) BEFORE any DMA is in flight: the atomic's return is then the only
-    // thing its s_waitcnt waits for
-    if (tid == 0) s_tile[0] = (int)atomicAdd(a.counter, 1u);
+    // Dynamic tile scheduler: workgroups take tiles from a device counter (zero before the launch) instead of the static
+    // b, b + grid, ...: in the multi-stream pipeline some CUs are held by other kernels' workgroups, the workgroups that
+    // ARE resident take the work and late starters find none.  Ids are fetched two tiles ahead (the next tile's patch is
+    // requested at the top of the current one).  The first two BEFORE any DMA is in flight: the atomics' returns are then
+    // the only thing their s_waitcnt waits for.
+    if (tid == 0) {
+        s_tile[2] = (int)atomicAdd(a.counter, 1u);
+        s_tile[0] = (int)atomicAdd(a.counter, 1u);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s_tile[0] >= ntiles) return;                        // a late starter: the resident workgroups took every tile
+    int t = __builtin_amdgcn_readfirstlane(s_tile[2]);
+    if (t >= ntiles) return;
+    if (tid < 64) reinterpret_cast<float*>(smem + kBiasOff)[tid] = a.bias[wres_channel(tid >> 4, tid & 15)];                                // a late starter: the resident workgroups took every tile
 
-    // ---- all nine weight slabs, once: piece p = 8 rows of one tap; lane l -> row l/8, physical chunk l%8 ----
+    // ---- all nine weight slabs, once: piece p = 8 LDS rows of one tap; lane l -> LDS row R = 8 (p & 7) + l/8 (which
+    //      holds output channel wres_channel(R / 16, R % 16)), physical chunk l%8 ----
     const int drow = lane >> 3, dchunk = lane & 7;
     {
         const int Ktot = 9 * 64;
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const int p = wave + 4 * i, tap = p >> 3, row = (p & 7) * 8 + drow;
-            dma16(a.w + (size_t)row * Ktot + tap * 64 + ((dchunk ^ (row & 7)) * 8), wlds + p * 1024);
+            const int ch = wres_channel(row >> 4, row & 15);
+            dma16(a.w + (size_t)ch * Ktot + tap * 64 + ((dchunk ^ (row & 7)) * 8), wlds + p * 1024);
         }
     }
     // ---- patch sources (relative to the tile origin): lane l of piece p feeds pixel q = 8p + l/8, chunk l%8 ^ f(q) ----
@@ -88,20 +111,25 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         const int py = q / 18, px = q - py * 18;
         p_rel[i] = py * a.in_row + px * a.in_pix + ((dchunk ^ (q & 7)) * 8);        // chunk swizzle q & 7: conflict-free ds_read_b128 (see conv_patch.hip)
     }
-    auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
-        img = t / tpi;
-        const int r = t - img * tpi;
+    auto tile_origin = [&](int tt, int& img, int& y0, int& x0) {
+        img = tt / tpi;
+        const int r = tt - img * tpi;
         y0 = (r / tpr) * 16; x0 = (r % tpr) * 16;
     };
-    auto issue_patch = [&](int t) {
+    auto issue_patch = [&](int tt, unsigned char* buf) {
         int img, y0, x0;
-        tile_origin(t, img, y0, x0);
+        tile_origin(tt, img, y0, x0);
         const uint16_t* base = in_ptr + (size_t)img * a.in_img + (size_t)y0 * a.in_row + (size_t)x0 * a.in_pix;
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
             const int p = wave + 4 * i;
-            if (p < kNDma) dma16(base + p_rel[i], patch + p * 1024);
+            if (p < kNDma) dma16(base + p_rel[i], buf + p * 1024);
         }
+    };
+    auto out_origin = [&](int tt) -> size_t {
+        int img, y0, x0;
+        tile_origin(tt, img, y0, x0);
+        return 2 * ((size_t)a.out_off + (size_t)img * a.out_img + (size_t)y0 * a.out_row + (size_t)x0 * a.out_pix);   // bytes
     };
 
     const int frow = lane & 15, fq = lane >> 4;
@@ -109,104 +137,70 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     const uint32_t w_lane = smem_base + frow * 128 + ((fq ^ (frow & 7)) * 16);       // ks = 0; ks = 1: ^ 64 on the low part
     const uint32_t w_lane1 = smem_base + frow * 128 + (((4 + fq) ^ (frow & 7)) * 16);
     const int qb = (wave * 4) * 18 + frow;
-    uint32_t xoff[9][4];
+    uint32_t xo[6][3];                      // patch pixel (4 wave + r, frow + dx), r = j + ky: 18 addresses serve the 9 x 4 (tap, j) pairs
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = qb + j * 18 + (tap / 3) * 18 + (tap % 3);
-            xoff[tap][j] = smem_base + kWAll + q * 128 + ((fq ^ (q & 7)) * 16);
+        for (int dx = 0; dx < 3; ++dx) {
+            const int q = qb + r * 18 + dx;
+            xo[r][dx] = smem_base + kWAll + q * 128 + ((fq ^ (q & 7)) * 16);
         }
+    // this lane's pixel (row 4 wave + j, column frow of the tile) and channel group: byte offset from the tile origin
+    const uint32_t lane_boff = (uint32_t)(((wave * 4) * a.out_row + frow * a.out_pix + fq * 8) * 2);
+    const uint32_t bias_lane = smem_base + kBiasOff + fq * 16;
+    constexpr bool has_res = RES, relu = RELU;
+    unsigned char* const out_ptr = reinterpret_cast<unsigned char*>(a.out);
+    const unsigned char* const res_ptr = reinterpret_cast<const unsigned char*>(a.res);
+    const int out_row_b = a.out_row * 2;
 
-    // bias of this lane's 4 x 4 channels, once
-    float4 bias_r[4];
+    uint4 resr[8];                          // residual of piece c = 2 j + h: channels 32 h + 8 fq .. + 7 of pixel row j
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bias_r[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + fq * 4);
-    // residual tile by LDS-DMA straight into the staging tile (same swizzled image the epilogue uses): piece p =
-    // pixels 8p..8p+7, lane l -> pixel 8p + l/8, physical chunk l%8 = logical chunk ^ (pixel & 7)
-    const bool has_res = a.res != nullptr;
-    auto issue_res = [&](int tt) {
-        int img, y0, x0;
-        tile_origin(tt, img, y0, x0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = wave + 4 * i, tp = p * 8 + drow;
-            const size_t o = (size_t)a.out_off + (size_t)img * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
-            dma16(a.res + o + ((dchunk ^ (tp & 7)) * 8), stage + p * 1024);
+    for (int c = 0; c < 8; ++c) resr[c] = make_uint4(0, 0, 0, 0);
+    // piece c of a finished tile (the bias went in as the accumulators' initial value): residual + ReLU, pack, one 16-byte
+    // store.  org = byte offset of the tile origin, wave-uniform: the address is scalar base + 32-bit lane offset.
+    auto epi_piece = [&](const f32x4 (&ap)[4][4], size_t org, int c) {
+        const int j = c >> 1, h = c & 1;
+        const f32x4 lo4 = ap[2 * h][j], hi4 = ap[2 * h + 1][j];
+        float v0 = lo4[0], v1 = lo4[1], v2 = lo4[2], v3 = lo4[3], v4 = hi4[0], v5 = hi4[1], v6 = hi4[2], v7 = hi4[3];
+        if constexpr (has_res) {
+            const uint4 r = resr[c];
+            v0 += Elem<F16>::lo(r.x); v1 += Elem<F16>::hi(r.x); v2 += Elem<F16>::lo(r.y); v3 += Elem<F16>::hi(r.y);
+            v4 += Elem<F16>::lo(r.z); v5 += Elem<F16>::hi(r.z); v6 += Elem<F16>::lo(r.w); v7 += Elem<F16>::hi(r.w);
         }
+        if constexpr (relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            v4 = fmaxf(v4, 0.f); v5 = fmaxf(v5, 0.f); v6 = fmaxf(v6, 0.f); v7 = fmaxf(v7, 0.f);
+        }
+        unsigned char* const base = out_ptr + org + (size_t)(j * out_row_b + h * 64);
+        *reinterpret_cast<uint4*>(base + lane_boff) =
+            make_uint4(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3), Elem<F16>::pack2(v4, v5), Elem<F16>::pack2(v6, v7));
     };
+    auto load_res = [&](size_t org, int c) {
+        const int j = c >> 1, h = c & 1;
+        const unsigned char* const base = res_ptr + org + (size_t)(j * out_row_b + h * 64);
+        resr[c] = *reinterpret_cast<const uint4*>(base + lane_boff);
+    };
+
     WSTAMP(0);
-    // Dynamic tile scheduler: workgroups take tiles from a device counter (zero before the launch) instead of the
-    // static b, b + grid, ...  The grid is one workgroup per CU, but in the multi-stream pipeline some CUs are held by
-    // other kernels' workgroups (a fit workgroup keeps its CU's LDS for 230 us): with static tiles the workgroups of
-    // those CUs start late and the launch takes two rounds (measured 43 us under contention vs 21 us alone); with the
-    // counter the workgroups that ARE resident take the work and late starters find none.
-    int t = s_tile[0];                                      // fetched before the weight DMA was issued (top of the kernel)
-    if (t < ntiles) issue_patch(t);
-    bool first = true;
-    while (t < ntiles) {
-        // weights (first tile) + this tile's patch have landed.  On later tiles the patch DMA was issued BEFORE the
-        // previous tile's 8 output stores per lane, and vmcnt counts stores too: leave those 8 in flight.
-        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        // (the staging tile may still be read by the previous tile's stores of OTHER waves: the barrier below orders
-        //  their LDS reads -- already complete, they waited lgkmcnt before storing -- against this tile's residual DMA)
-        __builtin_amdgcn_s_barrier();
-        if (first) { WSTAMP(1); } else { WSTAMP(5); }
-        first = false;
-        // next tile id: issued now, read after the K loop.  Inline asm: hipcc's atomicAdd waits vmcnt(0) right behind the
-        // instruction (wave-aggregated lowering), which would park this wave on the previous tile's stores as well.
-        unsigned next_raw = 0;
-        if (tid == 0) {
-            const unsigned one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(next_raw) : "v"(a.counter), "v"(one) : "memory");
-        }
-        if (has_res) issue_res(t);                            // lands during the K loop
+    issue_patch(t, patch);
+    size_t prev_org = 0;
+    unsigned next_raw = 0;
+    int ntile_done = 0;
 
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // ---- 9 taps, no barrier: fragments of tap+1 are read while the 32 MFMAs of tap run ----
-        bf16x8 wfr[2][2][4], xfr[2][2][4];
-#define WRES_READ(TAP, SET)                                                                    \
-    {                                                                                          \
-        const uint32_t w0_ = w_lane + (TAP) * kWSlab, w1_ = w_lane1 + (TAP) * kWSlab;          \
-        wfr[SET][0][0] = lds_read_b128<0>(w0_);                                                \
-        wfr[SET][0][1] = lds_read_b128<2048>(w0_);                                             \
-        wfr[SET][0][2] = lds_read_b128<4096>(w0_);                                             \
-        wfr[SET][0][3] = lds_read_b128<6144>(w0_);                                             \
-        wfr[SET][1][0] = lds_read_b128<0>(w1_);                                                \
-        wfr[SET][1][1] = lds_read_b128<2048>(w1_);                                             \
-        wfr[SET][1][2] = lds_read_b128<4096>(w1_);                                             \
-        wfr[SET][1][3] = lds_read_b128<6144>(w1_);                                             \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                        \
-            xfr[SET][0][j] = lds_read_b128<0>(xoff[TAP][j]);                                   \
-            xfr[SET][1][j] = lds_read_b128<0>(xoff[TAP][j] ^ 64);                              \
-        }                                                                                      \
-    }
-#define WRES_MFMA(SET)                                                                         \
-    {                                                                                          \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                       \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                  \
-                    acc[i][j] = Elem<F16>::mfma(wfr[SET][kk][i], xfr[SET][kk][j], acc[i][j]); \
-    }
-        // One tap: the 16 fragment reads of tap TAP (set SET) go out between the 32 MFMAs of the previous tap (set SET^1),
-        // one read per MFMA pair and all of them within the first half, so that their issue slots and their latency sit
-        // under the matrix pipe.  Every sched_barrier pins that order: hipcc otherwise gathers the reads in front and sinks
-        // the register-only MFMAs BELOW the wait (measured: the wave then waits for reads it has just issued).
+    // One tile on patch buffer BUF: acc receives its products, ap holds the previous tile's (stored piece by piece here).
 #define WRES_SB __builtin_amdgcn_sched_barrier(0);
 #define WRES_RW(SET, KK, I, TAP) wfr[SET][KK][I] = lds_read_b128<(I) * 2048>(((KK) ? w_lane1 : w_lane) + (TAP) * kWSlab);
-#define WRES_RX(SET, KK, J, TAP) xfr[SET][KK][J] = lds_read_b128<0>(xoff[TAP][J] ^ ((KK) * 64));
+#define WRES_RX(SET, KK, J, TAP) xfr[SET][KK][J] = lds_read_b128<POFF>(xo[(J) + (TAP) / 3][(TAP) % 3] ^ ((KK) * 64));
 #define WRES_M2(S1, KK, I, J)                                                                  \
         WRES_SB                                                                                \
         acc[I][J] = Elem<F16>::mfma(wfr[S1][KK][I], xfr[S1][KK][J], acc[I][J]);                \
         acc[I][(J) + 1] = Elem<F16>::mfma(wfr[S1][KK][I], xfr[S1][KK][(J) + 1], acc[I][(J) + 1]); \
         WRES_SB
-#define WRES_STEP(TAP, SET)                                                                    \
+    // One tap: the 16 fragment reads of tap TAP (set SET) go out between the first 16 MFMAs of the previous tap (set
+    // SET^1), one read pair per MFMA pair, pinned by sched_barriers (hipcc otherwise gathers the reads in front and sinks
+    // the register-only MFMAs BELOW the wait).  The last 16 MFMAs have no reads beside them: the previous tile's epilogue
+    // piece PIECE and the residual load that refills its registers are left to the scheduler inside that region.
+#define WRES_STEP(TAP, SET, PIECE)                                                             \
     {                                                                                          \
         WRES_RW(SET, 0, 0, TAP) WRES_RW(SET, 0, 1, TAP) WRES_M2((SET) ^ 1, 0, 0, 0)             \
         WRES_RW(SET, 0, 2, TAP) WRES_RW(SET, 0, 3, TAP) WRES_M2((SET) ^ 1, 0, 0, 2)             \
@@ -216,75 +210,105 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         WRES_RW(SET, 1, 2, TAP) WRES_RW(SET, 1, 3, TAP) WRES_M2((SET) ^ 1, 0, 2, 2)             \
         WRES_RX(SET, 1, 0, TAP) WRES_RX(SET, 1, 1, TAP) WRES_M2((SET) ^ 1, 0, 3, 0)             \
         WRES_RX(SET, 1, 2, TAP) WRES_RX(SET, 1, 3, TAP) WRES_M2((SET) ^ 1, 0, 3, 2)             \
-        WRES_M2((SET) ^ 1, 1, 0, 0) WRES_M2((SET) ^ 1, 1, 0, 2) WRES_M2((SET) ^ 1, 1, 1, 0) WRES_M2((SET) ^ 1, 1, 1, 2) \
-        WRES_M2((SET) ^ 1, 1, 2, 0) WRES_M2((SET) ^ 1, 1, 2, 2) WRES_M2((SET) ^ 1, 1, 3, 0) WRES_M2((SET) ^ 1, 1, 3, 2) \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                       \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                   \
+                acc[i_][j_] = Elem<F16>::mfma(wfr[(SET) ^ 1][1][i_], xfr[(SET) ^ 1][1][j_], acc[i_][j_]); \
+        if constexpr (PREV) epi_piece(ap, prev_org, PIECE);                                    \
+        if constexpr (has_res) load_res(org, PIECE);                                           \
+        _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                    \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA ... */          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      /* ... three VALU under it */ \
+        }                                                                                      \
+        WRES_SB                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
         WRES_SB                                                                                \
     }
-        WRES_READ(0, 0)
+    auto tile = [&](auto buf_c, auto prev_c, f32x4 (&acc)[4][4], const f32x4 (&ap)[4][4]) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool PREV = decltype(prev_c)::value;
+        constexpr int POFF = BUF * kPatch;
+        // this tile's patch (requested a tile ago), its residual registers and the id of the tile after next have landed;
+        // the previous tile's stores have left
+        // (the id of the tile after next was requested a tile ago into an ACCUMULATION register, see below)
+        if constexpr (PREV) {
+            unsigned got;
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, %1" : "=v"(got) : "a"(next_raw) : "memory");
+            if (tid == 0) s_tile[BUF] = (int)got;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave has left the other buffer
+        if (ntile_done == 0) { WSTAMP(1); } else if (ntile_done == 1) { WSTAMP(4); }
+        const int tn = __builtin_amdgcn_readfirstlane(s_tile[BUF]);
+        if (tn < ntiles) issue_patch(tn, patch + (BUF ^ 1) * kPatch);
+        {
+            // Next id: a returning atomic whose result is not needed for a whole tile.  Inline asm, because hipcc's own
+            // atomic waits for the return at once (wave-aggregated lowering, or a copy of the result), which would park the
+            // wave on the patch DMA just issued.  hipcc treats an asm output as written at ASMEND and may move it before
+            // the data has arrived (it did: a stale tile id, found as a memory fault at 512 tiles) -- so the result goes
+            // to an AGPR, which the register allocator has no reason to touch before the asm above reads it, and the
+            // statement has no branch around it (lane 0 of wave 0 is selected through EXEC; EXEC = 0 issues nothing).
+            const int only = __builtin_amdgcn_readfirstlane((wave == 0 && tn < ntiles) ? 1 : 0);
+            const unsigned one = 1u;
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\t"
+                         "global_atomic_add %0, %3, %4, off sc0\n\ts_mov_b64 exec, %1"
+                         : "=a"(next_raw), "=&s"(saved) : "s"(only), "v"(a.counter), "a"(one) : "memory");
+        }
+        const size_t org = out_origin(t);
+        // accumulators start at the bias (tile i, register e of this lane = channel row 16 i + 4 fq + e of the bias block)
+        {
+            f32x4 b0, b1, b2, b3;       // loads and their wait in ONE statement: hipcc treats asm outputs as written at ASMEND
+            asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+                         "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(bias_lane) : "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[0][j] = b0; acc[1][j] = b1; acc[2][j] = b2; acc[3][j] = b3; }
+        }
+        bf16x8 wfr[2][2][4], xfr[2][2][4];
+        // tap 0 fragments
+        WRES_RW(0, 0, 0, 0) WRES_RW(0, 0, 1, 0) WRES_RW(0, 0, 2, 0) WRES_RW(0, 0, 3, 0)
+        WRES_RX(0, 0, 0, 0) WRES_RX(0, 0, 1, 0) WRES_RX(0, 0, 2, 0) WRES_RX(0, 0, 3, 0)
+        WRES_RW(0, 1, 0, 0) WRES_RW(0, 1, 1, 0) WRES_RW(0, 1, 2, 0) WRES_RW(0, 1, 3, 0)
+        WRES_RX(0, 1, 0, 0) WRES_RX(0, 1, 1, 0) WRES_RX(0, 1, 2, 0) WRES_RX(0, 1, 3, 0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        WRES_STEP(1, 1) WRES_STEP(2, 0) WRES_STEP(3, 1) WRES_STEP(4, 0)
-        WRES_STEP(5, 1) WRES_STEP(6, 0) WRES_STEP(7, 1) WRES_STEP(8, 0)
-        WRES_MFMA(0)
+        WRES_STEP(1, 1, 0) WRES_STEP(2, 0, 1) WRES_STEP(3, 1, 2) WRES_STEP(4, 0, 3)
+        WRES_STEP(5, 1, 4) WRES_STEP(6, 0, 5) WRES_STEP(7, 1, 6) WRES_STEP(8, 0, 7)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Elem<F16>::mfma(wfr[0][kk][i], xfr[0][kk][j], acc[i][j]);
+        if (ntile_done == 0) { WSTAMP(2); } else if (ntile_done == 1) { WSTAMP(5); }
+        ++ntile_done;
+        prev_org = org;
+        t = tn;
+    };
+    f32x4 accA[4][4], accB[4][4];
+    // the last tile's epilogue has no K loop to hide under
+    auto flush = [&](const f32x4 (&ap)[4][4]) {
+        if constexpr (has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 8; ++c) epi_piece(ap, prev_org, c);
+        WSTAMP(7);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    tile(B0{}, std::false_type{}, accA, accB);              // the first tile has no predecessor to store
+    if (t >= ntiles) flush(accA);
+    else
+        for (;;) {
+            tile(B1{}, std::true_type{}, accB, accA);
+            if (t >= ntiles) { flush(accB); break; }
+            tile(B0{}, std::true_type{}, accA, accB);
+            if (t >= ntiles) { flush(accA); break; }
+        }
 #undef WRES_STEP
 #undef WRES_M2
 #undef WRES_RX
 #undef WRES_RW
 #undef WRES_SB
-#undef WRES_MFMA
-#undef WRES_READ
-
-        if (t == (int)blockIdx.x) { WSTAMP(2); } else { WSTAMP(6); }
-        if (tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(next_raw) : : "memory");     // the atomic's return (and the residual DMA, long landed)
-            s_tile[0] = (int)next_raw;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                         // every wave is done with the patch; next tile id published
-        const int tn = s_tile[0];
-        if (tn < ntiles) issue_patch(tn);                     // next tile's patch streams in under the epilogue
-
-        // ---- epilogue through the LDS staging tile (see conv_patch.hip): whole 128-byte lines to and from HBM ----
-        int img, y0, x0;
-        tile_origin(t, img, y0, x0);
-        auto pix_off = [&](int tp) -> size_t {
-            return (size_t)a.out_off + (size_t)img * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
-        };
-        if (has_res) {
-            // residual DMA (8 pieces) is older than the next-patch DMA (<= 11 pieces) just issued
-            if (tn < ntiles) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tp = wave * 64 + j * 16 + frow;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int loff = tp * 128 + (((i * 2 + (fq >> 1)) ^ (tp & 7)) * 16) + (fq & 1) * 8;
-                const float4 bv = bias_r[i];
-                const f32x4 c = acc[i][j];
-                float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
-                if (has_res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(stage + loff);      // own slot: read, then overwrite
-                    v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
-                }
-                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                *reinterpret_cast<uint2*>(stage + loff) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = tid + it * 256, tp = idx >> 3, c = idx & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(stage + tp * 128 + ((c ^ (tp & 7)) * 16));
-            *reinterpret_cast<uint4*>(a.out + pix_off(tp) + c * 8) = v;
-        }
-        if (t == (int)blockIdx.x) { WSTAMP(3); } else { WSTAMP(7); }
-        // the staging tile is rewritten only after the next tile's first barrier
-        t = tn;
-    }
 }
 
 }  // namespace
@@ -298,26 +322,38 @@ bool conv_wres_supported(const ConvArgs& a) {
 
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
     SPSP_REQUIRE(conv_wres_supported(a), "conv_wres: needs a 3x3 stride-1 64->64 convolution on a map that is a multiple of 16 wide");
-    SPSP_TRY(ensure_dynamic_lds<&conv3x3_wres_kernel<false>>(kLds));
-    SPSP_TRY(ensure_dynamic_lds<&conv3x3_wres_kernel<true>>(kLds));
     const int ntiles = a.M / 256;
-    const int grid = ntiles < num_cus ? ntiles : num_cus;       // persistent: one workgroup per CU (147 KB of LDS each)
+    const int grid = ntiles < num_cus ? ntiles : num_cus;       // persistent: one workgroup per CU (154 KB of LDS each)
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
         (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_wres_kernel<false><<<dim3(grid), 256, kLds, st>>>(b);
+        SPSP_TRY((ensure_dynamic_lds<&conv3x3_wres_kernel<true, true, true>>(kLds)));
+        SPSP_TRY((ensure_dynamic_lds<&conv3x3_wres_kernel<true, false, true>>(kLds)));
+        if (b.res) conv3x3_wres_kernel<true, true, true><<<dim3(grid), 256, kLds, st>>>(b);
+        else conv3x3_wres_kernel<true, false, true><<<dim3(grid), 256, kLds, st>>>(b);
         (void)hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "wres grid=%d tiles=%d: weights+patch landed %llu | K loop %llu | epilogue %llu | tile2 wait %llu | K loop %llu | epilogue %llu | total %llu\n",
-                grid, ntiles, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[5] - h[3], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+        fprintf(stderr, "wres grid=%d tiles=%d: weights+patch landed %llu | K loop %llu | tile2 top %llu | K loop (+ epilogue 1) %llu | last epilogue %llu | total %llu\n",
+                grid, ntiles, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[5] - h[4], h[7] - h[5], h[7] - h[0]);
         (void)hipFree(b.dbg);
         return SPSP_OK;
     }
 #endif
-    if (a.f16) conv3x3_wres_kernel<true><<<dim3(grid), 256, kLds, st>>>(a);
-    else conv3x3_wres_kernel<false><<<dim3(grid), 256, kLds, st>>>(a);
+    auto go = [&](auto f16_c, auto res_c, auto relu_c) -> int {
+        constexpr auto kern = &conv3x3_wres_kernel<decltype(f16_c)::value, decltype(res_c)::value, decltype(relu_c)::value>;
+        SPSP_TRY(ensure_dynamic_lds<kern>(kLds));
+        kern<<<dim3(grid), 256, kLds, st>>>(a);
+        return SPSP_OK;
+    };
+    auto pick_relu = [&](auto f16_c, auto res_c) -> int {
+        return a.relu ? go(f16_c, res_c, std::true_type{}) : go(f16_c, res_c, std::false_type{});
+    };
+    auto pick_res = [&](auto f16_c) -> int {
+        return a.res ? pick_relu(f16_c, std::true_type{}) : pick_relu(f16_c, std::false_type{});
+    };
+    SPSP_TRY(a.f16 ? pick_res(std::true_type{}) : pick_res(std::false_type{}));
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
