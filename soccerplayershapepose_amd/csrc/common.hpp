@@ -1,6 +1,7 @@
 // Shared host-side plumbing for libspsp.so (gfx950 only; no CUDA/HIP dual paths).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -115,20 +116,53 @@ struct spsp_ctx {
 };
 
 namespace spsp {
-// Brackets the launches issued during its lifetime with two events when profiling is enabled.
+// Profiling events of the scope the current thread is inside (nullptr: none / profiling off).
+struct ProfLaunch { hipEvent_t start, stop; bool single, used; };
+inline thread_local ProfLaunch* tl_prof = nullptr;
+
+// Times the launches issued during its lifetime when profiling is enabled.
+//   single = true : the scope holds exactly ONE launch, issued through spsp::launch_kernel() below, which hands the two events to
+//                   hipExtLaunchKernelGGL -- they then carry the kernel's own begin / end timestamps (what rocprofv3's
+//                   kernel trace reports), not the stream's idle time and event packets around it (~2-4 us per launch,
+//                   a quarter of a 10 us convolution);
+//   single = false: legacy bracket, an event recorded before and after whatever the scope launches.
 struct ProfScope {
-    spsp_ctx* ctx; hipStream_t st; hipEvent_t stop = nullptr;
-    ProfScope(spsp_ctx* c, int id, hipStream_t s) : ctx(c), st(s) {
+    ProfLaunch pl{nullptr, nullptr, false, false};
+    hipStream_t st;
+    bool active = false;
+    ProfScope(spsp_ctx* c, int id, hipStream_t s, bool single = false) : st(s) {
         if (!c || !c->prof_on || (c->prof_only >= 0 && c->prof_only != id)) return;
         hipEvent_t ev[2];
         for (auto& e : ev) {
             if (!c->prof_free.empty()) { e = c->prof_free.back(); c->prof_free.pop_back(); }
             else if (hipEventCreate(&e) != hipSuccess) return;
         }
-        (void)hipEventRecord(ev[0], st);
-        stop = ev[1];
+        pl = {ev[0], ev[1], single, false};
+        active = true;
+        if (single) tl_prof = &pl;
+        else (void)hipEventRecord(ev[0], st);
         c->prof_recs.push_back({id, ev[0], ev[1], st});
     }
-    ~ProfScope() { if (stop) (void)hipEventRecord(stop, st); }
+    ~ProfScope() {
+        if (!active) return;
+        if (pl.single) {
+            tl_prof = nullptr;
+            if (!pl.used) { (void)hipEventRecord(pl.start, st); (void)hipEventRecord(pl.stop, st); }   // nothing was launched
+        } else {
+            (void)hipEventRecord(pl.stop, st);
+        }
+    }
 };
+
+// kernel<<<grid, block, lds, st>>>(args...) -- through the profiling events of the enclosing single-launch ProfScope, if any
+template <class... KArgs, class... Args>
+inline void launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+    ProfLaunch* const p = tl_prof;
+    if (p && p->single && !p->used) {
+        p->used = true;
+        hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, p->start, p->stop, 0, static_cast<KArgs>(args)...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, static_cast<KArgs>(args)...);
+    }
+}
 }  // namespace spsp

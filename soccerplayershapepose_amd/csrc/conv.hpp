@@ -28,7 +28,7 @@ struct ConvArgs {
     int relu;
     float* part;             // split-K: fp32 slabs [splitk][M][N] (conv_ring only)
     int splitk;              // 1 = no split
-    unsigned int* counter;   // conv_wres: device word, zero before the launch -- dynamic tile scheduler (atomicAdd)
+    unsigned int* counter;   // conv_wres: eight device words, 128 bytes apart, zero before the launch -- dynamic tile scheduler
     int f16;                 // element type of in / w / res / out: 0 = bf16, 1 = fp16 (conv_elem.hpp)
     int xcd_n;               // conv_patch: XCDs along the channel blocks (tile order; set by launch_conv_patch)
     // conv_ring: an optional SECOND convolution by the same workgroups -- the 1x1 stride-2 downsample of a residual stage rides

@@ -413,7 +413,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    conv3x3_patch_kernel<W8, F16, DB><<<dim3(grid), 512, lds, st>>>(a);
+    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB>, dim3(grid), dim3(512), lds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

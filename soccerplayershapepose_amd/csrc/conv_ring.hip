@@ -215,7 +215,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     const int tiles = (a.M / BM) * (a.N / BN);
     SPSP_REQUIRE(!a.pool_out || BM == a.Ho * a.Wo, "conv_ring: fused avg-pool needs one image per M tile");
     SPSP_TRY((ensure_dynamic_lds<&conv_ring_kernel<BM, BN, NS, F16>>((int)lds)));
-    conv_ring_kernel<BM, BN, NS, F16><<<dim3(tiles), 256, lds, st>>>(a);
+    launch_kernel(&conv_ring_kernel<BM, BN, NS, F16>, dim3(tiles), dim3(256), lds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

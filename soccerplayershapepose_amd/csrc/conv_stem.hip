@@ -370,8 +370,8 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
         return SPSP_OK;
     }
 #endif
-    if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
-    else conv1_pool_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+    if (f16) launch_kernel(&conv1_pool_kernel<true, 0>, dim3(B * a.bands), dim3(256), kLds, st, a);
+    else launch_kernel(&conv1_pool_kernel<false, 0>, dim3(B * a.bands), dim3(256), kLds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

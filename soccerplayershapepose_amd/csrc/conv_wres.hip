@@ -22,6 +22,7 @@
 // Workgroup = 4 waves (one per SIMD), wave tile 64 px x 64 ch on v_mfma_f32_16x16x32 (weights = A operand, pixels = B
 // operand).  LDS: weights 73.7 KB + 2 x patch 41 KB = 155.7 KB.
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "conv.hpp"
@@ -55,8 +56,10 @@ constexpr int kLds = kBiasOff + 256 + 16;        // 157 968 B (last 16 B: tile-i
 
 #ifdef SPSP_CONV_STAMPS
 #define WSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
+#define WSTAMP_WG(i) if (a.dbg && tid == 0) a.dbg[16 + 4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime()
 #else
 #define WSTAMP(i)
+#define WSTAMP_WG(i)
 #endif
 
 // output channel held by accumulator tile i, MFMA row r (= 4 fq + e) -- see the header
@@ -80,9 +83,16 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     // ARE resident take the work and late starters find none.  Ids are fetched two tiles ahead (the next tile's patch is
     // requested at the top of the current one).  The first two BEFORE any DMA is in flight: the atomics' returns are then
     // the only thing their s_waitcnt waits for.
+    WSTAMP_WG(0);
+    // Workgroups b, b + 8, ... (one XCD under round-robin dispatch -- a speed assumption only) share ONE of eight counters,
+    // each on its own 128-byte line, and own the tiles = class (mod 8): with a single counter the 256 workgroups' first
+    // fetches serialised at one L2 line (stamps: ~12k cycles mean between kernel entry and the first DMA).
+    const int nclass = gridDim.x < 8 ? (int)gridDim.x : 8, cls = (int)blockIdx.x % nclass;
+    unsigned int* const ctr = a.counter + 32 * cls;
     if (tid == 0) {
-        s_tile[2] = (int)atomicAdd(a.counter, 1u);
-        s_tile[0] = (int)atomicAdd(a.counter, 1u);
+        const int r0 = (int)atomicAdd(ctr, 2u);             // the first two ids in one fetch
+        s_tile[2] = r0 * nclass + cls;
+        s_tile[0] = (r0 + 1) * nclass + cls;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         if constexpr (PREV) {
             unsigned got;
             asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, %1" : "=v"(got) : "a"(next_raw) : "memory");
-            if (tid == 0) s_tile[BUF] = (int)got;
+            if (tid == 0) s_tile[BUF] = (int)got * nclass + cls;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave has left the other buffer
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
             unsigned long long saved;
             asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\t"
                          "global_atomic_add %0, %3, %4, off sc0\n\ts_mov_b64 exec, %1"
-                         : "=a"(next_raw), "=&s"(saved) : "s"(only), "v"(a.counter), "a"(one) : "memory");
+                         : "=a"(next_raw), "=&s"(saved) : "s"(only), "v"(ctr), "a"(one) : "memory");
         }
         const size_t org = out_origin(t);
         // accumulators start at the bias (tile i, register e of this lane = channel row 16 i + 4 fq + e of the bias block)
@@ -292,6 +302,10 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) epi_piece(ap, prev_org, c);
         WSTAMP(7);
+        WSTAMP_WG(1);
+#ifdef SPSP_CONV_STAMPS
+        if (a.dbg && tid == 0) a.dbg[16 + 4 * blockIdx.x + 2] = (unsigned long long)ntile_done;
+#endif
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
@@ -327,16 +341,35 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
-        (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
+        const size_t nd = 16 + 4 * (size_t)grid;
+        (void)hipMalloc(&b.dbg, nd * sizeof(unsigned long long));
+        (void)hipMemset(b.dbg, 0, nd * sizeof(unsigned long long));
         SPSP_TRY((ensure_dynamic_lds<&conv3x3_wres_kernel<true, true, true>>(kLds)));
         SPSP_TRY((ensure_dynamic_lds<&conv3x3_wres_kernel<true, false, true>>(kLds)));
         if (b.res) conv3x3_wres_kernel<true, true, true><<<dim3(grid), 256, kLds, st>>>(b);
         else conv3x3_wres_kernel<true, false, true><<<dim3(grid), 256, kLds, st>>>(b);
         (void)hipDeviceSynchronize();
-        unsigned long long h[16];
-        (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> hv(nd);
+        (void)hipMemcpy(hv.data(), b.dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        const unsigned long long* h = hv.data();
         fprintf(stderr, "wres grid=%d tiles=%d: weights+patch landed %llu | K loop %llu | tile2 top %llu | K loop (+ epilogue 1) %llu | last epilogue %llu | total %llu\n",
                 grid, ntiles, h[1] - h[0], h[2] - h[1], h[4] - h[2], h[5] - h[4], h[7] - h[5], h[7] - h[0]);
+        {   // every workgroup: start / end against the earliest start, tiles done
+            unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
+            int hist[8] = {0};
+            for (int g = 0; g < grid; ++g) { const unsigned long long s0 = h[16 + 4 * g]; if (s0 && s0 < t0) t0 = s0; }
+            double dur = 0;
+            for (int g = 0; g < grid; ++g) {
+                const unsigned long long s0 = h[16 + 4 * g], e0 = h[16 + 4 * g + 1];
+                if (e0 > t1) t1 = e0;
+                if (s0 > smax) smax = s0;
+                dur += (double)(e0 - s0);
+                const int nt = (int)h[16 + 4 * g + 2];
+                hist[nt < 7 ? nt : 7]++;
+            }
+            fprintf(stderr, "  all workgroups: first start -> last start %llu | first start -> last end %llu | mean residency %.0f | tiles/wg histogram 0:%d 1:%d 2:%d 3:%d 4+:%d\n",
+                    smax - t0, t1 - t0, dur / grid, hist[0], hist[1], hist[2], hist[3], hist[4] + hist[5] + hist[6] + hist[7]);
+        }
         (void)hipFree(b.dbg);
         return SPSP_OK;
     }
@@ -344,7 +377,7 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t st) {
     auto go = [&](auto f16_c, auto res_c, auto relu_c) -> int {
         constexpr auto kern = &conv3x3_wres_kernel<decltype(f16_c)::value, decltype(res_c)::value, decltype(relu_c)::value>;
         SPSP_TRY(ensure_dynamic_lds<kern>(kLds));
-        kern<<<dim3(grid), 256, kLds, st>>>(a);
+        launch_kernel(kern, dim3(grid), dim3(256), kLds, st, a);
         return SPSP_OK;
     };
     auto pick_relu = [&](auto f16_c, auto res_c) -> int {

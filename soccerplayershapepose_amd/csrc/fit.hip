@@ -161,12 +161,12 @@ int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg,
     P.weight = std::exp(-P.log_var);
     P.select_mode = cfg->select_mode;
     P.num_levels = s->num_levels;
-    ProfScope ps(ctx, kKFit, as_stream(stream));
+    ProfScope ps(ctx, kKFit, as_stream(stream), true);
     unsigned long long* dbg = nullptr;
 #ifdef SPSP_FIT_STAMPS
     if (getenv("SPSP_FIT_DEBUG")) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
 #endif
-    fit_kernel<<<B, kFitLanes, 0, as_stream(stream)>>>(P, s->fitc, s->parents, s->level_joints, s->d_level_start,
+    launch_kernel(&fit_kernel, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->fitc, s->parents, s->level_joints, s->d_level_start,
                                                 s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist,
                                                 l2e_hist, param_hist, dbg);
     if (dbg) {

@@ -82,8 +82,8 @@ extern "C" {
 int spsp_rot6d_to_rotmat(spsp_ctx* ctx, const float* pose6d, int n, float* R, void* stream) {
     SPSP_REQUIRE(ctx && pose6d && R && n >= 0, "spsp_rot6d_to_rotmat: bad arguments");
     if (n == 0) return SPSP_OK;
-    spsp::ProfScope ps(ctx, spsp::kKRot6d, spsp::as_stream(stream));
-    rot6d_kernel<<<(n + 255) / 256, 256, 0, spsp::as_stream(stream)>>>(pose6d, n, R);
+    spsp::ProfScope ps(ctx, spsp::kKRot6d, spsp::as_stream(stream), true);
+    spsp::launch_kernel(&rot6d_kernel, dim3((n + 255) / 256), dim3(256), 0, spsp::as_stream(stream), pose6d, n, R);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }

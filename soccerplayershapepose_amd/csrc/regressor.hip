@@ -15,6 +15,8 @@ constexpr int kWH = SPSP_PROXY_WH, kCin = SPSP_PROXY_C, kPad = SPSP_PROXY_PAD;
 constexpr int kWHp = SPSP_PROXY_NATIVE_H, kWWp = SPSP_PROXY_NATIVE_W;   // 262 rows x 264 columns
 constexpr size_t kNativeElems = (size_t)kWHp * kWWp * kCin;
 constexpr int kFeat = 512, kNPar = 157, kHid = 512;
+// per-forward counter block: 128-byte lines 0..31 = tile schedulers of the four conv_wres launches (8 each), 32..39 = IEF barriers
+constexpr int kCounterWords = 40 * 32;
 
 struct ConvDesc { const char* name; const char* bn; int cout, cin, k, stride; };
 const ConvDesc kConvs[SPSP_NUM_CONVS] = {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
     const int b = (s >> 3) ? bB : bA;                        // ... for this player
     const bool live = b < a.B;
     const int rA = bA < a.B ? bA : a.B - 1, rB = bB < a.B ? bB : a.B - 1;   // idle lanes recompute the last player (no stores)
-    unsigned int* const counter = a.counters + pb;
+    unsigned int* const counter = a.counters + pb * 32;      // one 128-byte line per counter
     unsigned int phase = 0;
 
     {   // weight slices -> LDS (rows 8g.. of each matrix are 16 KB contiguous; fc3 has 157 rows)
@@ -285,14 +287,14 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     a.kw_steps = d.k; a.chunks = d.cin / 64; a.nsteps = d.k * d.k * a.chunks;
     a.relu = relu;
     a.splitk = 1;
-    a.counter = r->counters + (r->next_counter < 15 ? r->next_counter : 15);
+    a.counter = r->counters + 32 * 8 * (r->next_counter < 3 ? r->next_counter : 3);   // 8 scheduler words (one per XCD class), a 128-byte line each
     if (conv_wres_supported(a)) {                      // layer1: 3x3 / 1, 64 -> 64, weights resident in LDS
         ++r->next_counter;
-        ProfScope ps(ctx, kKConvWres, st);
+        ProfScope ps(ctx, kKConvWres, st, true);
         return launch_conv_wres(a, ctx->num_cus, st);
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
-        ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st);
+        ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
         return launch_conv_patch(a, r->patch_db[L], st);
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
@@ -301,7 +303,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     const int bm = (rt == kRing64x128s3 || rt == kRing64x64s4) ? 64 : 128;
     const int bn = (rt == kRing128x64s3 || rt == kRing128x64s4 || rt == kRing64x64s4) ? 64 : 128;
     SPSP_REQUIRE(a.M % bm == 0 && a.N % bn == 0, "regressor: conv %s at batch %d does not tile (%d x %d)", d.name, B, bm, bn);
-    ProfScope ps(ctx, kKConvRing, st);
+    ProfScope ps(ctx, kKConvRing, st, true);
     return launch_conv_ring(a, rt, st);
 }
 
@@ -390,7 +392,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     for (int L = 0; L < 4; ++L)
         for (int j = 0; j < 3; ++j)
             TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
-    TRY(r->pool.alloc(&r->counters, 16, true));
+    TRY(r->pool.alloc(&r->counters, kCounterWords, true));
     {   // plan of the residual stages (ONE plan; measured at 32 crops)
         const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};
         // two patch buffers where the layer has fewer tiles than the chip has CUs (layer3, layer4); layer2 fills every
@@ -440,11 +442,11 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         x0 = r->x0;
     }
     // tile-scheduler counters of this forward's persistent launches
-    SPSP_HIP_CHECK(hipMemsetAsync(r->counters, 0, 16 * sizeof(unsigned int), st));
+    SPSP_HIP_CHECK(hipMemsetAsync(r->counters, 0, kCounterWords * sizeof(unsigned int), st));
     r->next_counter = 0;
     // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
     {
-        ProfScope ps(ctx, kKStem, st);
+        ProfScope ps(ctx, kKStem, st, true);
         TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, st));
     }
     r->stage_ptr[0] = nullptr;
@@ -487,11 +489,11 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         ia.feats = r->feats; ia.w1f = r->w1f; ia.w13 = r->w13; ia.w2 = r->w2; ia.w3 = r->w3;
         ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
         ia.h1 = r->h1; ia.s = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
-        ia.counters = r->counters + 8;           // words 8..15 of the per-forward counter block (zeroed above)
+        ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed above)
         ia.B = B; ia.iters = r->ief_iters;
         SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel>(kIefLds));
-        ProfScope ps(ctx, kKIefFc, st);
-        ief_fused_kernel<<<dim3(kIefG, npb), 256, kIefLds, st>>>(ia);
+        ProfScope ps(ctx, kKIefFc, st, true);
+        launch_kernel(&ief_fused_kernel, dim3(kIefG, npb), dim3(256), kIefLds, st, ia);
     } else {
         ProfScope ps(ctx, kKIefMisc, st);
         ief_init_only_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, cam, pose6d, betas);

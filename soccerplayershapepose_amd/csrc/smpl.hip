@@ -233,18 +233,18 @@ int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
     SPSP_REQUIRE(B >= 0 && B <= s->max_batch, "spsp_smpl_forward: B=%d exceeds max_batch=%d", B, s->max_batch);
     if (B == 0 || (!verts && !joints)) return SPSP_OK;
     hipStream_t st = as_stream(stream);
-    { ProfScope ps(ctx, kKSmplChain, st);
-    smpl_chain_kernel<<<B, 64, 0, st>>>(R, betas, s->jconst, s->parents, s->level_joints, s->d_level_start,
+    { ProfScope ps(ctx, kKSmplChain, st, true);
+    launch_kernel(&smpl_chain_kernel, dim3(B), dim3(64), 0, st, R, betas, s->jconst, s->parents, s->level_joints, s->d_level_start,
                                         s->num_levels, s->ws_A, s->ws_coef, joints); }
     SPSP_HIP_CHECK(hipGetLastError());
     float* v = verts ? verts : s->ws_verts;
     dim3 grid((kV + 63) / 64, (B + kPB - 1) / kPB);
-    { ProfScope ps(ctx, kKSmplSkin, st);
-      smpl_skin_kernel<<<grid, kSkinThreads, 0, st>>>(s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v); }
+    { ProfScope ps(ctx, kKSmplSkin, st, true);
+      launch_kernel(&smpl_skin_kernel, grid, dim3(kSkinThreads), 0, st, s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v); }
     SPSP_HIP_CHECK(hipGetLastError());
     if (joints) {
-        ProfScope ps(ctx, kKSmplJoints, st);
-        smpl_extra_joints_kernel<<<B, 256, 0, st>>>(v, s->pick_ids, s->csr_ptr, s->csr_col, s->csr_val, joints);
+        ProfScope ps(ctx, kKSmplJoints, st, true);
+        launch_kernel(&smpl_extra_joints_kernel, dim3(B), dim3(256), 0, st, v, s->pick_ids, s->csr_ptr, s->csr_col, s->csr_val, joints);
         SPSP_HIP_CHECK(hipGetLastError());
     }
     return SPSP_OK;
