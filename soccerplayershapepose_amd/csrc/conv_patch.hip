@@ -23,11 +23,13 @@
 //   W >= 16 : tile = 16 x 16 pixels of one image, patch 18 x 18; wave w owns rows 4w..4w+3, MFMA tile j = one row.
 //   W == 8  : tile = 4 whole 8 x 8 images, patch 4 x (10 x 10); wave w owns image w, MFMA tile j = rows 2j, 2j+1.
 //
-// One structure (the per-tap-ring forms of the first round are gone): 8 waves; wave pairs (w, w+4 -- the two waves of
-// one SIMD) split every 64-deep K-step in halves and exchange accumulators through LDS at the end; GROUPED weight ring --
-// the three slabs of a kernel row land together in one half of a 2 x 3-slab ring, one vmcnt(0) + barrier per three
-// taps; with DB (template flag, the default for layer3 / layer4) TWO patch buffers, so the next 64-channel chunk's
-// patch lands under the nine taps of the current one (131 / 150 KB of LDS instead of 89 / 99 KB).
+// One structure (the per-tap-ring forms of the first round are gone): 2 NPG waves = NPG 64-pixel groups x 2 K-halves; wave
+// pairs (w, w + NPG) split every 64-deep K-step in halves and exchange accumulators through LDS at the end; GROUPED weight
+// ring -- the three slabs of a kernel row land together in one third of a 3 x 3-slab ring, one counted vmcnt + barrier
+// per three taps, and the slabs of group g+2 are requested at the top of group g: a group computes for 768 (128-pixel
+// tile) or 1536 cycles, an L2 -> LDS fetch takes ~2k under load, and with the two-group ring of the first version every
+// group waited for its own weights.  With DB (template flag, the default for layer3 / layer4) TWO patch buffers, so the
+// next 64-channel chunk's patch lands under the nine taps of the current one.
 // Inside a tap the 8 fragment reads of the NEXT tap are issued between the first MFMA pairs of the current one (two
 // register sets, every position pinned by sched_barrier): hipcc otherwise gathers the reads in front and sinks the
 // register-only MFMAs below the lgkmcnt wait, so that a wave waits for reads it has just issued (round 1 ran that way:
@@ -75,31 +77,34 @@ constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
 template <bool W8>
 __device__ __forceinline__ int patch_swz(int q) { return W8 ? ((q >> 1) & 7) : (q & 7); }
 
-template <bool W8>
+// NPG = 64-pixel groups per tile: 4 (256-pixel tile, 8 waves) or 2 (128-pixel tile, 4 waves -- twice the workgroups, for
+// the layers whose 256-pixel tiles leave most of the chip idle: layer3 has 128 of them, layer4 64)
+template <bool W8, int NPG>
 struct Geo {
-    static constexpr int NW = 8;                                  // waves per workgroup
+    static constexpr int NW = 2 * NPG;                            // waves per workgroup (pixel groups x 2 K-halves)
+    static constexpr int TPIX = 64 * NPG;                         // output pixels per tile
     static constexpr int PW = W8 ? 10 : 18;                       // patch row pitch in pixels
-    static constexpr int NPIX = W8 ? 400 : 324;                   // patch pixels
+    static constexpr int NPIX = W8 ? 100 * NPG : (4 * NPG + 2) * 18;   // patch pixels
     static constexpr int NDMA = (NPIX + 7) / 8;                   // 8 pixels per wave-instruction
     static constexpr int PATCH = NDMA * 8 * kPixB;                // bytes (padded to whole DMA pieces)
     static constexpr int DPW = (NDMA + NW - 1) / NW;              // patch DMA instructions per wave
 };
 
-// One workgroup: 256 pixels x 64 channels.  grid = (M/256) * (N/64).
-template <bool W8, bool F16, bool DB>
-__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
-    using G = Geo<W8>;
-    constexpr int PW = G::PW, kNS = 6, NW = G::NW, KS = 2;
+// One workgroup: TPIX pixels x 64 channels.  grid = (M/TPIX) * (N/64).
+template <bool W8, bool F16, bool DB, int NPG>
+__global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs a) {
+    using G = Geo<W8, NPG>;
+    constexpr int PW = G::PW, kNS = 9, NW = G::NW, KS = 2;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const ring = smem;                              // kNS x 8 KB weight stages
     unsigned char* const patch0 = smem + kNS * kWStage;            // the patch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_id & 3;                                  // which 64 pixels of the tile
-    const int kw = wave_id >> 2;                                   // KS == 2: which 32-deep half of every K-step
+    const int wave = wave_id & (NPG - 1);                          // which 64 pixels of the tile
+    const int kw = wave_id / NPG;                                  // KS == 2: which 32-deep half of every K-step
     const int W = a.Wo;                                            // == Ho, == input W (stride 1)
-    const int mt = a.M / 256, nb = a.N / 64;
+    const int mt = a.M / G::TPIX, nb = a.N / 64;
     int m_tile, n_blk;
     {
         // blocks b, b+8, b+16 ... share an XCD (round-robin dispatch; a speed assumption only): XCD x = b & 7 owns the
@@ -118,12 +123,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
 
     // tile origin in the padded input (element offset of patch pixel (0,0), channel 0)
     int img0, y0 = 0, x0 = 0;
-    if constexpr (W8) { img0 = m_tile * 4; }
+    if constexpr (W8) { img0 = m_tile * NPG; }
     else {
-        const int tpr = W / 16, tpi = tpr * tpr;                   // tiles per row / per image
+        constexpr int TH = 4 * NPG;                                // tile height (its width is 16)
+        const int tpr = W / 16, tpi = tpr * (W / TH);              // tiles per row / per image
         img0 = m_tile / tpi;
         const int t = m_tile - img0 * tpi;
-        y0 = (t / tpr) * 16; x0 = (t % tpr) * 16;
+        y0 = (t / tpr) * TH; x0 = (t % tpr) * 16;
     }
     const int nch_tot = a.chunks, nchunks = a.chunks, ch0 = 0;     // Cin / 64
     const uint16_t* const in_ptr = a.in;                           // scalar copies (keep the kernarg struct out of lambdas)
@@ -135,7 +141,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
     int p_src[G::DPW];                                             // element offsets into a.in (chunk 0)
 #pragma unroll
     for (int i = 0; i < G::DPW; ++i) {
-        const int p = wave_id + NW * i;
+        int p = wave_id + NW * i;
+        p = p < G::NDMA ? p : G::NDMA - 1;
         int q = p * 8 + drow;
         q = q < G::NPIX ? q : G::NPIX - 1;                         // tail lanes re-read the last pixel (harmless)
         int off;
@@ -151,12 +158,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
     auto issue_patch = [&](int ch, int pbuf = 0) {
 #pragma unroll
         for (int i = 0; i < G::DPW; ++i) {
-            const int p = wave_id + NW * i;
-            if (p < G::NDMA) dma16(in_ptr + p_src[i] + (ch0 + ch) * 64, patch0 + pbuf * G::PATCH + p * 1024);
+            int p = wave_id + NW * i;
+            p = p < G::NDMA ? p : G::NDMA - 1;       // every wave issues exactly DPW pieces (counted vmcnt waits): the surplus repeats the last one
+            dma16(in_ptr + p_src[i] + (ch0 + ch) * 64, patch0 + pbuf * G::PATCH + p * 1024);
         }
     };
     // ---- weight ring sources: stage = [64 n][64 k] of K-step g (tap-major, chunk-minor: g = tap*nchunks + ch) ----
-    constexpr int LPS = 2 / KS;                                    // weight pieces per wave per stage (8 per stage)
+    constexpr int LPS = 8 / NW;                                    // weight pieces per wave per stage (8 per stage)
     const uint16_t* w_src[LPS];
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
@@ -202,9 +210,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
 
     // ---- software pipeline: the 8 fragment reads of tap t+1 are issued between the MFMAs of tap t (two register
     // sets; a tap's set is static because the tap loop is fully unrolled and 9 is odd: set = (9 ch + tap) & 1).
-    // Ring = 2 halves x 3 slabs.  Group g = (chunk, kernel row): at its start every wave has its own DMA pieces of
-    // group g landed (vmcnt(0): nothing younger is in flight yet); after the barrier the slabs of group g+1 are issued
-    // into the half group g-1 was read from, then the three taps run back to back -- 48 MFMAs per wave between barriers.
+    // Ring = 3 groups x 3 slabs.  Group g = (chunk, kernel row) sits in ring third g % 3 = its kernel row; at its top
+    // every wave waits (counted) for its own DMA pieces of group g, and after the barrier the slabs of group g+2 are issued
+    // into the third group g-1 was read from, then the three taps run back to back -- 48 MFMAs per wave between barriers.
     // (macros, not lambdas: the fragment arrays must be indexed by literal constants to stay in registers)
     bf16x8 wfr[2][4], xfr[2][4];
     const uint32_t w_lane_k = smem_base + (w_lane ^ (kw * 64));
@@ -243,38 +251,44 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
         auto issue_group = [&](int g) {
             const int gch = g / 3, gr = g - gch * 3;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nch_tot + ch0 + gch, (g & 1) * 3 + t);
+            for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nch_tot + ch0 + gch, gr * 3 + t);
         };
         issue_group(0);
-#define SPSP_GROUP(R, P0, CH, HALF)                                                                       \
+        if (ngroups > 1) issue_group(1);
+        // At the top of group g its slabs (requested two groups ago) must have landed; what this wave issued after them may
+        // stay in flight: the slabs of group g+1 and, with two patch buffers, the next chunk's patch when that was
+        // requested one group ago (at a chunk's first group).
+#define SPSP_GROUP(R, P0, CH)                                                                             \
     {                                                                                                     \
         const int g_ = (CH) * 3 + (R);                                                                    \
         const uint32_t pboff_ = DB ? ((CH) & 1) * G::PATCH : 0;   /* this chunk's patch buffer */          \
-        wait_vmcnt<0>();                                                                                  \
+        if (g_ + 1 >= ngroups) wait_vmcnt<0>();                                                           \
+        else if (DB && (R) == 1 && (CH) + 1 < nchunks) wait_vmcnt<3 * LPS + G::DPW>();                    \
+        else wait_vmcnt<3 * LPS>();                                                                       \
         __builtin_amdgcn_s_barrier();                                                                     \
         if (!DB && (R) == 0 && (CH) > 0) {                                                                \
             /* one patch buffer, chunk boundary: every wave is past its last read of the old patch; refill it, run */ \
             /* the pending MFMAs of the previous tap underneath, then wait for the patch (older than the slabs) */ \
             issue_patch(CH);                                                                              \
-            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
+            if (g_ + 2 < ngroups) issue_group(g_ + 2);                                                    \
             SPSP_MFMA_SET(((P0) & 1) ^ 1)                                                                 \
-            if (g_ + 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
+            if (g_ + 2 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
             __builtin_amdgcn_s_barrier();                                                                 \
-            SPSP_GTAP(0, (P0) & 1, (HALF) * 3 + 0, true)                                                  \
+            SPSP_GTAP(0, (P0) & 1, (R) * 3 + 0, true)                                                     \
         } else {                                                                                          \
             /* two patch buffers, first group of a chunk: every wave is past its reads of chunk CH-1, whose buffer */ \
             /* now takes chunk CH+1 -- it has the nine taps of this chunk to land (no wait at chunk boundaries)    */ \
             if (DB && (R) == 0 && (CH) + 1 < nchunks) issue_patch((CH) + 1, ((CH) + 1) & 1);              \
-            if (g_ + 1 < ngroups) issue_group(g_ + 1);                                                    \
-            SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (HALF) * 3 + 0, (R) == 0 && (CH) == 0)       \
+            if (g_ + 2 < ngroups) issue_group(g_ + 2);                                                    \
+            SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (R) * 3 + 0, (R) == 0 && (CH) == 0)          \
         }                                                                                                 \
-        SPSP_GTAP((R) * 3 + 1, ((R) * 3 + 1 + (P0)) & 1, (HALF) * 3 + 1, false)                           \
-        SPSP_GTAP((R) * 3 + 2, ((R) * 3 + 2 + (P0)) & 1, (HALF) * 3 + 2, false)                           \
+        SPSP_GTAP((R) * 3 + 1, ((R) * 3 + 1 + (P0)) & 1, (R) * 3 + 1, false)                              \
+        SPSP_GTAP((R) * 3 + 2, ((R) * 3 + 2 + (P0)) & 1, (R) * 3 + 2, false)                              \
     }
-        // group parity: g = 3 ch + r -> half = g & 1; a chunk has 3 groups, so the half of row r flips with ch
+        // ring slot of group g = 3 ch + r is r (three groups of three slabs); the register-set parity of a tap flips with ch
         for (int ch = 0; ch < nchunks; ch += 2) {
-            SPSP_GROUP(0, 0, ch, 0) SPSP_GROUP(1, 0, ch, 1) SPSP_GROUP(2, 0, ch, 0)
-            if (ch + 1 < nchunks) { SPSP_GROUP(0, 1, ch + 1, 1) SPSP_GROUP(1, 1, ch + 1, 0) SPSP_GROUP(2, 1, ch + 1, 1) }
+            SPSP_GROUP(0, 0, ch) SPSP_GROUP(1, 0, ch) SPSP_GROUP(2, 0, ch)
+            if (ch + 1 < nchunks) { SPSP_GROUP(0, 1, ch + 1) SPSP_GROUP(1, 1, ch + 1) SPSP_GROUP(2, 1, ch + 1) }
         }
 #undef SPSP_GROUP
     }
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
         };
         if (kw == 0) put(std::integral_constant<int, 2>{}); else put(std::integral_constant<int, 0>{});
         __syncthreads();
-        const int partner = wave_id ^ 4;
+        const int partner = wave_id ^ NPG;
         auto get = [&](auto KEEP) {
             constexpr int k = decltype(KEEP)::value;
 #pragma unroll
@@ -320,19 +334,19 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
     //   A  residual tile  global -> LDS   (16 B per lane, 8 lanes = one pixel's 128-B channel block)
     //   C  per-lane math, residual from LDS, packed bf16 into an LDS output tile
     //   E  output tile    LDS -> global   (16 B per lane, whole lines)
-    // LDS tiles are [256 px][128 B] with the 16-byte chunk XOR-swizzled by the pixel (bank-conflict-free both ways).
+    // LDS tiles are [TPIX px][128 B] with the 16-byte chunk XOR-swizzled by the pixel (bank-conflict-free both ways).
     // tile pixel tp = wave*64 + j*16 + frow.
     __syncthreads();                                   // ring / patch / exchange buffers are dead from here on
     unsigned char* const resT = smem;
-    unsigned char* const outT = smem + 256 * 128;
+    unsigned char* const outT = smem + G::TPIX * 128;
     auto pix_off = [&](int tp) -> size_t {
         if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + (tp >> 6)) * a.out_img + (size_t)((tp >> 3) & 7) * a.out_row + (size_t)(tp & 7) * a.out_pix;
         else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
     };
-    constexpr int NTHR = 512;
+    constexpr int NTHR = 64 * NW;
     if (a.res) {
 #pragma unroll
-        for (int it = 0; it < 2048 / NTHR; ++it) {
+        for (int it = 0; it < G::TPIX * 8 / NTHR; ++it) {
             const int idx = tid + it * NTHR, tp = idx >> 3, c = idx & 7;
             const uint4 v = *reinterpret_cast<const uint4*>(a.res + pix_off(tp) + n_blk + c * 8);
             *reinterpret_cast<uint4*>(resT + tp * 128 + ((c ^ (tp & 7)) * 16)) = v;
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
     if (a.out) {
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 2048 / NTHR; ++it) {
+        for (int it = 0; it < G::TPIX * 8 / NTHR; ++it) {
             const int idx = tid + it * NTHR, tp = idx >> 3, c = idx & 7;
             const uint4 v = *reinterpret_cast<const uint4*>(outT + tp * 128 + ((c ^ (tp & 7)) * 16));
             *reinterpret_cast<uint4*>(a.out + pix_off(tp) + n_blk + c * 8) = v;
@@ -392,35 +406,36 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const ConvArgs a) {
     CSTAMP(6);
 }
 
-template <bool W8, bool F16, bool DB>
+template <bool W8, bool F16, bool DB, int NPG>
 int launch_t(const ConvArgs& a, hipStream_t st) {
-    using G = Geo<W8>;
-    constexpr size_t lds = (size_t)6 * kWStage + (DB ? 2 : 1) * G::PATCH;
-    static_assert(lds >= 2 * 256 * 128, "epilogue staging (residual + output tile) / K-half exchange need 64 KB");
-    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB>>((int)lds)));
-    const int grid = (a.M / 256) * (a.N / 64);
+    using G = Geo<W8, NPG>;
+    constexpr size_t lds = (size_t)9 * kWStage + (DB ? 2 : 1) * G::PATCH;
+    static_assert(lds <= 160 * 1024, "one CU has 160 KB of LDS");
+    static_assert(lds >= 2 * G::TPIX * 128 && lds >= (size_t)G::NW * 8192, "epilogue staging (residual + output tile) / K-half exchange");
+    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG>>((int)lds)));
+    const int grid = (a.M / G::TPIX) * (a.N / 64);
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
         (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_patch_kernel<W8, F16, DB><<<dim3(grid), 512, lds, st>>>(b);
+        conv3x3_patch_kernel<W8, F16, DB, NPG><<<dim3(grid), 64 * G::NW, lds, st>>>(b);
         (void)hipDeviceSynchronize();
         unsigned long long h[16];
         (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "patch<W8=%d,DB=%d> chunks=%d wgs=%d: K loop %llu | K-half exchange + residual staging %llu | epilogue + stores %llu | total %llu cycles\n",
-                (int)W8, (int)DB, a.chunks, grid, h[4] - h[0], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d> chunks=%d wgs=%d: K loop %llu | K-half exchange + residual staging %llu | epilogue + stores %llu | total %llu cycles\n",
+                (int)W8, (int)DB, NPG, a.chunks, grid, h[4] - h[0], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
         (void)hipFree(b.dbg);
         return SPSP_OK;
     }
 #endif
-    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB>, dim3(grid), dim3(512), lds, st, a);
+    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG>, dim3(grid), dim3(64 * G::NW), lds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
 
-template <bool W8, bool DB>
+template <bool W8, bool DB, int NPG>
 int launch(const ConvArgs& a, hipStream_t st) {
-    return a.f16 ? launch_t<W8, true, DB>(a, st) : launch_t<W8, false, DB>(a, st);
+    return a.f16 ? launch_t<W8, true, DB, NPG>(a, st) : launch_t<W8, false, DB, NPG>(a, st);
 }
 
 }  // namespace
@@ -435,8 +450,8 @@ bool conv_patch_supported(const ConvArgs& a) {
 // How the 8 XCDs are laid over the (pixel tiles) x (channel blocks) grid: XN of them along the channel blocks.  An XCD
 // pulls its share of the weights (1 / XN) and of the input (XN / 8) through the fabric into its own L2; the split with
 // the fewest bytes wins (layer2: 8 x 1, layer4: 2 x 4).
-int conv_patch_xcd_n(const ConvArgs& a) {
-    const int mt = a.M / 256, nb = a.N / 64;
+int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels) {
+    const int mt = a.M / tile_pixels, nb = a.N / 64;
     const double wbytes = (double)a.N * a.nsteps * 64 * 2, xbytes = (double)a.M * a.chunks * 64 * 2;
     int best = 0;
     double best_b = 0;
@@ -449,13 +464,19 @@ int conv_patch_xcd_n(const ConvArgs& a) {
     return best;      // 0: no split fits (the kernel falls back to channel-block-fastest over the whole grid)
 }
 
-int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, hipStream_t stream) {
+int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, hipStream_t stream) {
     SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
     SPSP_REQUIRE(!a0.pool_out || a0.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
+    SPSP_REQUIRE(tile_pixels == 256 || tile_pixels == 128, "conv_patch: tile of %d pixels", tile_pixels);
     ConvArgs a = a0;
-    a.xcd_n = conv_patch_xcd_n(a);
-    if (a.Wo == 8) return two_patch_buffers ? launch<true, true>(a, stream) : launch<true, false>(a, stream);
-    return two_patch_buffers ? launch<false, true>(a, stream) : launch<false, false>(a, stream);
+    a.xcd_n = conv_patch_xcd_n(a, tile_pixels);
+    const bool db = two_patch_buffers;
+    if (tile_pixels == 256) {
+        if (a.Wo == 8) return launch<true, false, 4>(a, stream);        // (two 50 KB patches + the 72 KB ring do not fit)
+        return db ? launch<false, true, 4>(a, stream) : launch<false, false, 4>(a, stream);
+    }
+    if (a.Wo == 8) return db ? launch<true, true, 2>(a, stream) : launch<true, false, 2>(a, stream);
+    return db ? launch<false, true, 2>(a, stream) : launch<false, false, 2>(a, stream);
 }
 
 }  // namespace spsp
