@@ -38,6 +38,7 @@
 // channel-block-fastest -- the channel blocks that share an input patch run on ONE XCD at the same time (one L2 fill
 // instead of N/64), and each XCD's L2 holds 1/XN of the weights.  The host picks XN per layer (fewest fabric bytes).
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 #include "conv.hpp"
@@ -69,10 +70,32 @@ constexpr int kWStage = 64 * 128;            // [64 n][64 k] bf16
 
 #ifdef SPSP_CONV_STAMPS
 #define CSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
+// cycles this wave spends at the top of the weight groups: in the counted vmcnt wait, and in the barrier behind it
+#define CS_DECL unsigned long long cs_t0_ = 0, cs_t1_ = 0, cs_wait_ = 0, cs_bar_ = 0;
+#define CS_BEGIN cs_t0_ = __builtin_amdgcn_s_memtime();
+#define CS_MID cs_t1_ = __builtin_amdgcn_s_memtime(); cs_wait_ += cs_t1_ - cs_t0_;
+#define CS_END cs_bar_ += __builtin_amdgcn_s_memtime() - cs_t1_;
+#define CS_STORE if (a.dbg && blockIdx.x == 8 && tid == 0) { a.dbg[8] = cs_wait_; a.dbg[9] = cs_bar_; }
+// diagnosis: splitk == -1 in the stamped build = no weight / patch DMA inside the loop (results are garbage; read the K-loop cycles)
+#define CS_NODMA (a.splitk == -1)
+// every workgroup: start / end on the 100 MHz constant clock (s_memtime is per XCD)
+#define CS_WG(i) if (a.dbg && tid == 0) a.dbg[16 + 2 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define CSTAMP(i)
+#define CS_DECL
+#define CS_BEGIN
+#define CS_MID
+#define CS_END
+#define CS_STORE
+#define CS_NODMA false
+#define CS_WG(i)
 #endif
 constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
+
+// Output channel (within the 64-channel block) of accumulator tile i, MFMA row r = 4 fq + e: the weight rows are loaded in
+// this order so that a lane ends up with 8 CONSECUTIVE channels of each of its pixels in tiles (2h, 2h+1) -- the epilogue
+// is then plain 16-byte loads and stores, four lanes covering an aligned 64-byte half line (no LDS staging).
+__host__ __device__ constexpr int acc_channel(int i, int r) { return 32 * (i >> 1) + 8 * (r >> 2) + 4 * (i & 1) + (r & 3); }
 
 template <bool W8>
 __device__ __forceinline__ int patch_swz(int q) { return W8 ? ((q >> 1) & 7) : (q & 7); }
@@ -100,6 +123,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     unsigned char* const patch0 = smem + kNS * kWStage;            // the patch
 
     const int tid = threadIdx.x, lane = tid & 63;
+    CS_WG(0)
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave = wave_id & (NPG - 1);                          // which 64 pixels of the tile
     const int kw = wave_id / NPG;                                  // KS == 2: which 32-deep half of every K-step
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
         const int row = (wave_id * LPS + i) * 8 + drow;
-        w_src[i] = w_ptr + (size_t)(n_blk + row) * Ktot + ((dchunk ^ (row & 7)) * 8);
+        w_src[i] = w_ptr + (size_t)(n_blk + acc_channel(row >> 4, row & 15)) * Ktot + ((dchunk ^ (row & 7)) * 8);   // LDS row 'row' holds that output channel
     }
     auto issue_w = [&](int g, int buf) {
 #pragma unroll
@@ -192,66 +216,119 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     else qb = (wave * 4) * 18 + frow;
     constexpr int QJ = W8 ? 20 : 18;
 
-    // LDS byte offsets of this lane's pixel fragments for every (tap, tile j), ks = 0 (ks = 1: chunk bit 2 flips).
-    // They do not depend on the chunk, so the 36 values live in registers for the whole kernel.
-    uint32_t xoff[9][4];
+    // LDS byte offsets of this lane's pixel fragments (chunk-independent: registers for the whole kernel).
+    //   W >= 16 : MFMA tile j of tap (ky, dx) is patch row j + ky shifted by dx pixels, so the three taps of a kernel COLUMN
+    //             read only 6 different fragments (rows 0..5): 18 addresses xo[dx][row], and a tap needs ONE new pixel
+    //             fragment beside its four weight fragments (the first tap of a column: four).  LDS reads per workgroup drop
+    //             by a quarter (24 -> 18 per three taps) -- they, not the MFMAs, set the pace of the loop: 8 waves x 8
+    //             ds_read_b128 x 8 cycles = the 512 cycles 16 MFMAs per wave take, before the LDS-DMA writes.
+    //   W == 8  : a fragment is two 8-pixel rows, a one-row shift is not a fragment: all 36 (tap, j) addresses.
+    constexpr bool ROWS = !W8;
+    uint32_t xoff[ROWS ? 3 : 9][ROWS ? 6 : 4];
+    if constexpr (ROWS) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = qb + j * QJ + (tap / 3) * PW + (tap % 3);
-            xoff[tap][j] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
-        }
+            for (int r = 0; r < 6; ++r) {
+                const int q = qb + r * PW + dx;
+                xoff[dx][r] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
+            }
+    } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = qb + j * QJ + (tap / 3) * PW + (tap % 3);
+                xoff[tap][j] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
+            }
+    }
 
-    // K order inside the kernel: chunk-major, tap-minor (patch of chunk ch serves 9 consecutive steps); the weight
-    // matrix is stored tap-major/chunk-minor like the implicit-GEMM kernels, so step (ch, tap) reads K-step
+    // K order inside the kernel: chunk-major, then the kernel's columns (ROWS) or rows (W8), then the other tap index; the
+    // weight matrix is stored tap-major/chunk-minor like the implicit-GEMM kernels, so step (ch, tap) reads K-step
     // g = tap * nchunks + ch.
     const int nsteps = 9 * nchunks;
 
-    // ---- software pipeline: the 8 fragment reads of tap t+1 are issued between the MFMAs of tap t (two register
-    // sets; a tap's set is static because the tap loop is fully unrolled and 9 is odd: set = (9 ch + tap) & 1).
-    // Ring = 3 groups x 3 slabs.  Group g = (chunk, kernel row) sits in ring third g % 3 = its kernel row; at its top
-    // every wave waits (counted) for its own DMA pieces of group g, and after the barrier the slabs of group g+2 are issued
-    // into the third group g-1 was read from, then the three taps run back to back -- 48 MFMAs per wave between barriers.
+    // ---- software pipeline: the fragment reads of step s+1 are issued between the MFMAs of step s (two weight register
+    // sets; a step's set is static because the step loop is fully unrolled and 9 is odd: set = (9 ch + s) & 1).
+    // Ring = 3 groups x 3 slabs.  Group g = (chunk, kernel column or row) sits in ring third g % 3; at its top every wave
+    // waits (counted) for its own DMA pieces of group g, and after the barrier the slabs of group g+2 are issued into the
+    // third group g-1 was read from, then the three taps run back to back -- 48 MFMAs per wave between barriers.
+    // Pixel fragments: xw[group parity][row 0..5] (ROWS) -- tap T of a group multiplies rows T..T+3 -- or xw[set][j] (W8).
     // (macros, not lambdas: the fragment arrays must be indexed by literal constants to stay in registers)
-    bf16x8 wfr[2][4], xfr[2][4];
+    bf16x8 wfr[2][4], xw[2][ROWS ? 6 : 4];
     const uint32_t w_lane_k = smem_base + (w_lane ^ (kw * 64));
 #define P_SB __builtin_amdgcn_sched_barrier(0);
+#ifdef SPSP_PATCH_NOREADS      // diagnosis only: the loop without its fragment reads (garbage results)
+#define P_RW(SET, I, SLOT) asm volatile("" : "=v"(wfr[SET][I]) : "v"(w_lane_k));
+#define P_RX(XP, XR, A0, A1) asm volatile("" : "=v"(xw[XP][XR]) : "v"(xoff[A0][A1] + pboff_));
+#else
 #define P_RW(SET, I, SLOT) wfr[SET][I] = lds_read_b128<(I) * 2048>(w_lane_k + (SLOT) * kWStage);
-#define P_RX(SET, J, TAP) xfr[SET][J] = lds_read_b128<0>(xoff[TAP][J] + pboff_);
-#define P_M2(S1, I, J, ON)                                                                                \
+#define P_RX(XP, XR, A0, A1) xw[XP][XR] = lds_read_b128<0>(xoff[A0][A1] + pboff_);
+#endif
+    // two MFMAs of the step whose weights are in set S1 and whose pixel fragments are xw[XP][XT + j]
+#define P_M2(S1, XP, XT, I, J, ON)                                                                        \
         P_SB                                                                                              \
         if (ON) {                                                                                         \
-            acc[I][J] = Elem<F16>::mfma(wfr[S1][I], xfr[S1][J], acc[I][J]);                               \
-            acc[I][(J) + 1] = Elem<F16>::mfma(wfr[S1][I], xfr[S1][(J) + 1], acc[I][(J) + 1]);             \
+            acc[I][J] = Elem<F16>::mfma(wfr[S1][I], xw[XP][(XT) + (J)], acc[I][J]);                       \
+            acc[I][(J) + 1] = Elem<F16>::mfma(wfr[S1][I], xw[XP][(XT) + (J) + 1], acc[I][(J) + 1]);       \
         }                                                                                                 \
         P_SB
-#define SPSP_MFMA_SET(S1)                                                                                 \
+#define SPSP_MFMA_SET(S1, XP, XT)                                                                         \
     {                                                                                                     \
-        P_M2(S1, 0, 0, true) P_M2(S1, 0, 2, true) P_M2(S1, 1, 0, true) P_M2(S1, 1, 2, true)               \
-        P_M2(S1, 2, 0, true) P_M2(S1, 2, 2, true) P_M2(S1, 3, 0, true) P_M2(S1, 3, 2, true)               \
-    }
-    // one tap: reads of tap TAP (-> set SET, weight slab SLOT) inside the MFMAs of the previous tap (set SET^1; none if FIRST)
-#define SPSP_GTAP(TAP, SET, SLOT, FIRST)                                                                  \
-    {                                                                                                     \
-        P_RW(SET, 0, SLOT) P_RW(SET, 1, SLOT) P_M2((SET) ^ 1, 0, 0, !(FIRST))                             \
-        P_RW(SET, 2, SLOT) P_RW(SET, 3, SLOT) P_M2((SET) ^ 1, 0, 2, !(FIRST))                             \
-        P_RX(SET, 0, TAP) P_RX(SET, 1, TAP) P_M2((SET) ^ 1, 1, 0, !(FIRST))                               \
-        P_RX(SET, 2, TAP) P_RX(SET, 3, TAP) P_M2((SET) ^ 1, 1, 2, !(FIRST))                               \
-        P_M2((SET) ^ 1, 2, 0, !(FIRST)) P_M2((SET) ^ 1, 2, 2, !(FIRST))                                   \
-        P_M2((SET) ^ 1, 3, 0, !(FIRST)) P_M2((SET) ^ 1, 3, 2, !(FIRST))                                   \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        P_M2(S1, XP, XT, 0, 0, true) P_M2(S1, XP, XT, 0, 2, true) P_M2(S1, XP, XT, 1, 0, true) P_M2(S1, XP, XT, 1, 2, true) \
+        P_M2(S1, XP, XT, 2, 0, true) P_M2(S1, XP, XT, 2, 2, true) P_M2(S1, XP, XT, 3, 0, true) P_M2(S1, XP, XT, 3, 2, true) \
+    }
+    // One step: its reads (weights -> set SET from ring slab SLOT; pixels: X4 = four fragments, else one) inside the MFMAs of
+    // the previous step (weights in set SET^1, pixels xw[MP][MT + j]; none if FIRST).
+    //   X4: xw[XP][XR..XR+3] <- xoff[A0][A1..A1+3];   one: xw[XP][XR] <- xoff[A0][A1]
+    // A step is only 16 MFMAs (256 cycles) long and every wave issues its reads at the same moment, so a step's last
+    // fragments are not back when its MFMAs are through (stamps: 31 cycles per MFMA with one wave per SIMD).  The reads go
+    // out in the order the NEXT step uses them -- pixels, W0, W1, W2, W3 -- and the waits are counted (LDS returns in
+    // order): a step ends when W0 has landed (ENDW = 3 reads may stay in flight) and waits for W1 / W2 / W3 right before
+    // the MFMAs of channel tile 1 / 2 / 3, by which time its own reads are in flight too (the counts below).
+    // The last step of a group ends with ENDW = 0: after the next barrier other waves overwrite the slab it read.
+#define P_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#define SPSP_GTAP(SET, SLOT, X4, XP, XR, A0, A1, MP, MT, FIRST, ENDW)                                     \
+    {                                                                                                     \
+        P_RX(XP, XR, A0, A1)                                                                              \
+        if (X4) { P_RX(XP, (XR) + 1, A0, (A1) + 1) } else { P_RW(SET, 0, SLOT) }                          \
+        P_M2((SET) ^ 1, MP, MT, 0, 0, !(FIRST))                                                           \
+        if (X4) { P_RX(XP, (XR) + 2, A0, (A1) + 2) P_RX(XP, (XR) + 3, A0, (A1) + 3) } else { P_RW(SET, 1, SLOT) P_RW(SET, 2, SLOT) } \
+        P_M2((SET) ^ 1, MP, MT, 0, 2, !(FIRST))                                                           \
+        P_WAIT(6)                                             /* previous W1 (behind it: W2, W3 + 4 new) */ \
+        if (X4) { P_RW(SET, 0, SLOT) P_RW(SET, 1, SLOT) } else { P_RW(SET, 3, SLOT) }                     \
+        P_M2((SET) ^ 1, MP, MT, 1, 0, !(FIRST))                                                           \
+        if (X4) { P_RW(SET, 2, SLOT) P_RW(SET, 3, SLOT) }                                                 \
+        P_M2((SET) ^ 1, MP, MT, 1, 2, !(FIRST))                                                           \
+        if (X4) { P_WAIT(9) } else { P_WAIT(6) }              /* previous W2 (behind it: W3 + 8 or 5 new) */ \
+        P_M2((SET) ^ 1, MP, MT, 2, 0, !(FIRST)) P_M2((SET) ^ 1, MP, MT, 2, 2, !(FIRST))                   \
+        if (X4) { P_WAIT(8) } else { P_WAIT(5) }              /* previous W3 */                            \
+        P_M2((SET) ^ 1, MP, MT, 3, 0, !(FIRST)) P_M2((SET) ^ 1, MP, MT, 3, 2, !(FIRST))                   \
+        P_WAIT(ENDW)                                                                                      \
         P_SB                                                                                              \
+    }
+    // Step T (0..2) of group R of a chunk with parity P0; s = 3 R + T is its place in the chunk, set = (s + P0) & 1.
+    //   ROWS: group = kernel column R, tap (ky = T, dx = R): pixels xw[GP][T..T+3], GP = (P0 + R) & 1; the step before it
+    //         used xw[GP][T-1 ..] (T > 0) or the previous group's xw[GP ^ 1][2 ..].
+    //   W8  : group = kernel row R, tap 3 R + T: pixels xw[set][0..3] <- xoff[tap][0..3].
+#define SPSP_STEP(R, T, P0, FIRST)                                                                        \
+    if constexpr (ROWS) {                                                                                 \
+        if constexpr ((T) == 0) SPSP_GTAP((3 * (R) + (P0)) & 1, (R) * 3, true, ((P0) + (R)) & 1, 0, R, 0, (((P0) + (R)) & 1) ^ 1, 2, FIRST, 3) \
+        else SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, (R) * 3 + (T), false, ((P0) + (R)) & 1, (T) + 3, R, (T) + 3, ((P0) + (R)) & 1, (T) - 1, FIRST, (T) == 2 ? 0 : 3) \
+    } else {                                                                                              \
+        SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, (R) * 3 + (T), true, (3 * (R) + (T) + (P0)) & 1, 0, 3 * (R) + (T), 0, ((3 * (R) + (T) + (P0)) & 1) ^ 1, 0, FIRST, (T) == 2 ? 0 : 3) \
     }
 
     CSTAMP(0);
+    CS_DECL
     issue_patch(0);
     {
         const int ngroups = 3 * nchunks;
         auto issue_group = [&](int g) {
             const int gch = g / 3, gr = g - gch * 3;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) issue_w((gr * 3 + t) * nch_tot + ch0 + gch, gr * 3 + t);
+            for (int t = 0; t < 3; ++t) issue_w((ROWS ? t * 3 + gr : gr * 3 + t) * nch_tot + ch0 + gch, gr * 3 + t);   // ROWS: taps (ky = t, dx = gr)
         };
         issue_group(0);
         if (ngroups > 1) issue_group(1);
@@ -262,28 +339,31 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     {                                                                                                     \
         const int g_ = (CH) * 3 + (R);                                                                    \
         const uint32_t pboff_ = DB ? ((CH) & 1) * G::PATCH : 0;   /* this chunk's patch buffer */          \
+        CS_BEGIN                                                                                          \
         if (g_ + 1 >= ngroups) wait_vmcnt<0>();                                                           \
         else if (DB && (R) == 1 && (CH) + 1 < nchunks) wait_vmcnt<3 * LPS + G::DPW>();                    \
         else wait_vmcnt<3 * LPS>();                                                                       \
+        CS_MID                                                                                            \
         __builtin_amdgcn_s_barrier();                                                                     \
+        CS_END                                                                                            \
         if (!DB && (R) == 0 && (CH) > 0) {                                                                \
             /* one patch buffer, chunk boundary: every wave is past its last read of the old patch; refill it, run */ \
             /* the pending MFMAs of the previous tap underneath, then wait for the patch (older than the slabs) */ \
             issue_patch(CH);                                                                              \
-            if (g_ + 2 < ngroups) issue_group(g_ + 2);                                                    \
-            SPSP_MFMA_SET(((P0) & 1) ^ 1)                                                                 \
+            if (g_ + 2 < ngroups && !CS_NODMA) issue_group(g_ + 2);                                       \
+            SPSP_MFMA_SET(((P0) & 1) ^ 1, ROWS ? ((P0) & 1) ^ 1 : ((P0) & 1) ^ 1, ROWS ? 2 : 0)           \
             if (g_ + 2 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
             __builtin_amdgcn_s_barrier();                                                                 \
-            SPSP_GTAP(0, (P0) & 1, (R) * 3 + 0, true)                                                     \
+            SPSP_STEP(0, 0, P0, true)                                                                     \
         } else {                                                                                          \
             /* two patch buffers, first group of a chunk: every wave is past its reads of chunk CH-1, whose buffer */ \
             /* now takes chunk CH+1 -- it has the nine taps of this chunk to land (no wait at chunk boundaries)    */ \
-            if (DB && (R) == 0 && (CH) + 1 < nchunks) issue_patch((CH) + 1, ((CH) + 1) & 1);              \
-            if (g_ + 2 < ngroups) issue_group(g_ + 2);                                                    \
-            SPSP_GTAP((R) * 3 + 0, ((R) * 3 + 0 + (P0)) & 1, (R) * 3 + 0, (R) == 0 && (CH) == 0)          \
+            if (DB && (R) == 0 && (CH) + 1 < nchunks && !CS_NODMA) issue_patch((CH) + 1, ((CH) + 1) & 1); \
+            if (g_ + 2 < ngroups && !CS_NODMA) issue_group(g_ + 2);                                       \
+            SPSP_STEP(R, 0, P0, (R) == 0 && (CH) == 0)                                                    \
         }                                                                                                 \
-        SPSP_GTAP((R) * 3 + 1, ((R) * 3 + 1 + (P0)) & 1, (R) * 3 + 1, false)                              \
-        SPSP_GTAP((R) * 3 + 2, ((R) * 3 + 2 + (P0)) & 1, (R) * 3 + 2, false)                              \
+        SPSP_STEP(R, 1, P0, false)                                                                        \
+        SPSP_STEP(R, 2, P0, false)                                                                        \
     }
         // ring slot of group g = 3 ch + r is r (three groups of three slabs); the register-set parity of a tap flips with ch
         for (int ch = 0; ch < nchunks; ch += 2) {
@@ -292,8 +372,12 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         }
 #undef SPSP_GROUP
     }
-    if ((nsteps - 1) & 1) SPSP_MFMA_SET(1) else SPSP_MFMA_SET(0)
+    // the last step: set = (nsteps - 1) & 1; ROWS: the last group has parity (3 nchunks - 1) & 1 and its tap 2 uses rows 2..5
+    if ((nsteps - 1) & 1) { if (ROWS && !((3 * nchunks - 1) & 1)) SPSP_MFMA_SET(1, 0, 2) else SPSP_MFMA_SET(1, 1, ROWS ? 2 : 0) }
+    else { if (ROWS && ((3 * nchunks - 1) & 1)) SPSP_MFMA_SET(0, 1, 2) else SPSP_MFMA_SET(0, 0, ROWS ? 2 : 0) }
+#undef SPSP_STEP
 #undef SPSP_GTAP
+#undef P_WAIT
 #undef SPSP_MFMA_SET
 #undef P_M2
 #undef P_RX
@@ -301,10 +385,31 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
 #undef P_SB
 
     CSTAMP(4);
+    CS_STORE
+    // ---- epilogue.  After the K-half exchange wave (kw, w) owns channel tiles 2 kw, 2 kw + 1 of its 64 pixels: with the
+    // permuted weight rows that is channels n_blk + 32 kw + 8 fq .. + 7 in this lane, 16 bytes per pixel.  The residual is
+    // loaded straight into registers before the exchange (its latency sits under the two barriers), the result is stored
+    // straight from registers: no staging tile, no barrier after the exchange.  tile pixel tp = wave*64 + j*16 + frow.
+    auto pix_off = [&](int tp) -> size_t {
+        if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + (tp >> 6)) * a.out_img + (size_t)((tp >> 3) & 7) * a.out_row + (size_t)(tp & 7) * a.out_pix;
+        else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
+    };
+    const int cbase = n_blk + 32 * kw + 8 * fq;
+    size_t poff[4];
+    uint4 resv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        poff[j] = pix_off(wave * 64 + j * 16 + frow) + cbase;
+        resv[j] = make_uint4(0, 0, 0, 0);
+        if (a.res) resv[j] = *reinterpret_cast<const uint4*>(a.res + poff[j]);
+    }
+    const float4 bias0 = *reinterpret_cast<const float4*>(a.bias + cbase), bias1 = *reinterpret_cast<const float4*>(a.bias + cbase + 4);
     {
         // Combine the two K-halves: wave (kw, w) keeps channel tiles i = 2kw, 2kw+1 and hands the other two to its
-        // partner through LDS (ring + patch are dead by now; 8 waves x 8 KB).  Static register indices only.
-        __syncthreads();
+        // partner through LDS (ring + patch are dead by now; NW waves x 8 KB).  Static register indices only.
+        // (raw barriers: __syncthreads() would also wait for the residual loads just issued)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         float* xch = reinterpret_cast<float*>(smem);
         auto put = [&](auto GIVE) {
             constexpr int g = decltype(GIVE)::value;
@@ -315,7 +420,8 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
                     *reinterpret_cast<f32x4*>(xch + ((size_t)(wave_id * 8 + ii * 4 + j) * 64 + lane) * 4) = acc[g + ii][j];
         };
         if (kw == 0) put(std::integral_constant<int, 2>{}); else put(std::integral_constant<int, 0>{});
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         const int partner = wave_id ^ NPG;
         auto get = [&](auto KEEP) {
             constexpr int k = decltype(KEEP)::value;
@@ -327,83 +433,48 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         };
         if (kw == 0) get(std::integral_constant<int, 0>{}); else get(std::integral_constant<int, 2>{});
     }
-
-    // ---- epilogue, staged through LDS so that HBM sees whole 128-byte lines ----
-    // In the accumulator a lane owns 4 channels (8 B) of a pixel: stored directly, one wave-instruction touches a
-    // quarter of 16 different lines (measured: 10-20 k cycles per workgroup, more than the whole K loop).  Instead:
-    //   A  residual tile  global -> LDS   (16 B per lane, 8 lanes = one pixel's 128-B channel block)
-    //   C  per-lane math, residual from LDS, packed bf16 into an LDS output tile
-    //   E  output tile    LDS -> global   (16 B per lane, whole lines)
-    // LDS tiles are [TPIX px][128 B] with the 16-byte chunk XOR-swizzled by the pixel (bank-conflict-free both ways).
-    // tile pixel tp = wave*64 + j*16 + frow.
-    __syncthreads();                                   // ring / patch / exchange buffers are dead from here on
-    unsigned char* const resT = smem;
-    unsigned char* const outT = smem + G::TPIX * 128;
-    auto pix_off = [&](int tp) -> size_t {
-        if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + (tp >> 6)) * a.out_img + (size_t)((tp >> 3) & 7) * a.out_row + (size_t)(tp & 7) * a.out_pix;
-        else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
-    };
-    constexpr int NTHR = 64 * NW;
-    if (a.res) {
-#pragma unroll
-        for (int it = 0; it < G::TPIX * 8 / NTHR; ++it) {
-            const int idx = tid + it * NTHR, tp = idx >> 3, c = idx & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(a.res + pix_off(tp) + n_blk + c * 8);
-            *reinterpret_cast<uint4*>(resT + tp * 128 + ((c ^ (tp & 7)) * 16)) = v;
-        }
-        __syncthreads();
-    }
+    CSTAMP(5);
     auto epilogue = [&](auto I0c) {
-        constexpr int I0 = decltype(I0c)::value, NI = 2;
-        float psum[NI][4];
+        constexpr int I0 = decltype(I0c)::value;
+        float psum[8];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) psum[i][0] = psum[i][1] = psum[i][2] = psum[i][3] = 0.f;
+        for (int e = 0; e < 8; ++e) psum[e] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int tp = wave * 64 + j * 16 + frow;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int nl = (I0 + i) * 16 + fq * 4;                 // channel within the 64-channel block
-                const int loff = tp * 128 + ((((I0 + i) * 2 + (fq >> 1)) ^ (tp & 7)) * 16) + (fq & 1) * 8;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n_blk + nl);
-                const f32x4 c = acc[I0 + i][j];
-                float v0 = c[0] + bv.x, v1 = c[1] + bv.y, v2 = c[2] + bv.z, v3 = c[3] + bv.w;
-                if (a.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(resT + loff);
-                    v0 += Elem<F16>::lo(rv.x); v1 += Elem<F16>::hi(rv.x); v2 += Elem<F16>::lo(rv.y); v3 += Elem<F16>::hi(rv.y);
-                }
-                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                *reinterpret_cast<uint2*>(outT + loff) = make_uint2(Elem<F16>::pack2(v0, v1), Elem<F16>::pack2(v2, v3));
-                psum[i][0] += v0; psum[i][1] += v1; psum[i][2] += v2; psum[i][3] += v3;
+            const f32x4 lo4 = acc[I0][j], hi4 = acc[I0 + 1][j];
+            float v[8] = {lo4[0] + bias0.x, lo4[1] + bias0.y, lo4[2] + bias0.z, lo4[3] + bias0.w,
+                          hi4[0] + bias1.x, hi4[1] + bias1.y, hi4[2] + bias1.z, hi4[3] + bias1.w};
+            if (a.res) {
+                const uint4 r = resv[j];
+                v[0] += Elem<F16>::lo(r.x); v[1] += Elem<F16>::hi(r.x); v[2] += Elem<F16>::lo(r.y); v[3] += Elem<F16>::hi(r.y);
+                v[4] += Elem<F16>::lo(r.z); v[5] += Elem<F16>::hi(r.z); v[6] += Elem<F16>::lo(r.w); v[7] += Elem<F16>::hi(r.w);
             }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) psum[e] += v[e];
+            if (a.out)
+                *reinterpret_cast<uint4*>(a.out + poff[j]) =
+                    make_uint4(Elem<F16>::pack2(v[0], v[1]), Elem<F16>::pack2(v[2], v[3]), Elem<F16>::pack2(v[4], v[5]), Elem<F16>::pack2(v[6], v[7]));
         }
         if constexpr (W8) {
             if (a.pool_out) {
                 // fused global average pool (resnet.py:157): this wave holds all 64 pixels of image img0 + wave
                 const int b = img0 + wave;
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = psum[i][r];
-                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                        if (frow == 0) a.pool_out[(size_t)b * a.N + n_blk + (I0 + i) * 16 + fq * 4 + r] = v * (1.0f / 64.0f);
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    float v = psum[e];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (frow == 0) a.pool_out[(size_t)b * a.N + cbase + e] = v * (1.0f / 64.0f);
+                }
             }
         }
     };
-    CSTAMP(5);
     if (kw == 0) epilogue(std::integral_constant<int, 0>{}); else epilogue(std::integral_constant<int, 2>{});
-    if (a.out) {
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < G::TPIX * 8 / NTHR; ++it) {
-            const int idx = tid + it * NTHR, tp = idx >> 3, c = idx & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(outT + tp * 128 + ((c ^ (tp & 7)) * 16));
-            *reinterpret_cast<uint4*>(a.out + pix_off(tp) + n_blk + c * 8) = v;
-        }
-    }
     CSTAMP(6);
+    CS_WG(1)
 }
 
 template <bool W8, bool F16, bool DB, int NPG>
@@ -411,19 +482,40 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, NPG>;
     constexpr size_t lds = (size_t)9 * kWStage + (DB ? 2 : 1) * G::PATCH;
     static_assert(lds <= 160 * 1024, "one CU has 160 KB of LDS");
-    static_assert(lds >= 2 * G::TPIX * 128 && lds >= (size_t)G::NW * 8192, "epilogue staging (residual + output tile) / K-half exchange");
+    static_assert(lds >= (size_t)G::NW * 8192, "K-half exchange");
     SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG>>((int)lds)));
     const int grid = (a.M / G::TPIX) * (a.N / 64);
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
-        (void)hipMalloc(&b.dbg, 16 * sizeof(unsigned long long));
-        conv3x3_patch_kernel<W8, F16, DB, NPG><<<dim3(grid), 64 * G::NW, lds, st>>>(b);
+        if (getenv("SPSP_PATCH_NODMA")) b.splitk = -1;
+        const size_t nd = 16 + 2 * (size_t)grid;
+        (void)hipMalloc(&b.dbg, nd * sizeof(unsigned long long));
+        (void)hipMemset(b.dbg, 0, nd * sizeof(unsigned long long));
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG>), dim3(grid), dim3(64 * G::NW), (unsigned)lds, st, e0, e1, 0, b);
         (void)hipDeviceSynchronize();
-        unsigned long long h[16];
-        (void)hipMemcpy(h, b.dbg, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d> chunks=%d wgs=%d: K loop %llu | K-half exchange + residual staging %llu | epilogue + stores %llu | total %llu cycles\n",
-                (int)W8, (int)DB, NPG, a.chunks, grid, h[4] - h[0], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        float kms = 0.f;
+        (void)hipEventElapsedTime(&kms, e0, e1);
+        std::vector<unsigned long long> hv(nd);
+        (void)hipMemcpy(hv.data(), b.dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        const unsigned long long* h = hv.data();
+        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d> chunks=%d wgs=%d: K loop %llu (of which weight wait %llu, barrier %llu) | residual loads + K-half exchange %llu | epilogue + stores %llu | total %llu cycles\n",
+                (int)W8, (int)DB, NPG, a.chunks, grid, h[4] - h[0], h[8], h[9], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        {
+            unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
+            double dur = 0;
+            for (int g = 0; g < grid; ++g) {
+                const unsigned long long s0 = h[16 + 2 * g], e = h[16 + 2 * g + 1];
+                if (s0 < t0) t0 = s0;
+                if (s0 > smax) smax = s0;
+                if (e > t1) t1 = e;
+                dur += (double)(e - s0);
+            }
+            fprintf(stderr, "  kernel %.2f us by its own timestamps; workgroups on the 100 MHz clock: first start -> last start %.2f us, first start -> last end %.2f us, mean residency %.2f us\n",
+                    kms * 1e3, (smax - t0) * 0.01, (t1 - t0) * 0.01, dur / grid * 0.01);
+        }
         (void)hipFree(b.dbg);
         return SPSP_OK;
     }
