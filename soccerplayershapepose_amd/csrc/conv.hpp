@@ -47,7 +47,7 @@ int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 
 // third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 px x 64 ch per workgroup
 bool conv_patch_supported(const ConvArgs& a);
-int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, hipStream_t stream);
+int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, int ring_groups, hipStream_t stream);
 
 // conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
 bool conv_wres_supported(const ConvArgs& a);

@@ -114,10 +114,11 @@ struct Geo {
 };
 
 // One workgroup: TPIX pixels x 64 channels.  grid = (M/TPIX) * (N/64).
-template <bool W8, bool F16, bool DB, int NPG>
+template <bool W8, bool F16, bool DB, int NPG, int NG>
 __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs a) {
     using G = Geo<W8, NPG>;
-    constexpr int PW = G::PW, kNS = 9, NW = G::NW, KS = 2;
+    constexpr int PW = G::PW, kNS = 3 * NG, NW = G::NW, KS = 2;   // NG = ring depth in groups of three slabs (2 or 3)
+    static_assert(NG == 2 || NG == 3, "ring depth");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const ring = smem;                              // kNS x 8 KB weight stages
     unsigned char* const patch0 = smem + kNS * kWStage;            // the patch
@@ -312,12 +313,14 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     //   ROWS: group = kernel column R, tap (ky = T, dx = R): pixels xw[GP][T..T+3], GP = (P0 + R) & 1; the step before it
     //         used xw[GP][T-1 ..] (T > 0) or the previous group's xw[GP ^ 1][2 ..].
     //   W8  : group = kernel row R, tap 3 R + T: pixels xw[set][0..3] <- xoff[tap][0..3].
+    // ring third of group R of a chunk with parity P0: g % NG with g = 3 ch + R
+#define P_GSLOT(R, P0) ((NG == 3 ? (R) : (((P0) + (R)) & 1)) * 3)
 #define SPSP_STEP(R, T, P0, FIRST)                                                                        \
     if constexpr (ROWS) {                                                                                 \
-        if constexpr ((T) == 0) SPSP_GTAP((3 * (R) + (P0)) & 1, (R) * 3, true, ((P0) + (R)) & 1, 0, R, 0, (((P0) + (R)) & 1) ^ 1, 2, FIRST, 3) \
-        else SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, (R) * 3 + (T), false, ((P0) + (R)) & 1, (T) + 3, R, (T) + 3, ((P0) + (R)) & 1, (T) - 1, FIRST, (T) == 2 ? 0 : 3) \
+        if constexpr ((T) == 0) SPSP_GTAP((3 * (R) + (P0)) & 1, P_GSLOT(R, P0), true, ((P0) + (R)) & 1, 0, R, 0, (((P0) + (R)) & 1) ^ 1, 2, FIRST, 3) \
+        else SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, P_GSLOT(R, P0) + (T), false, ((P0) + (R)) & 1, (T) + 3, R, (T) + 3, ((P0) + (R)) & 1, (T) - 1, FIRST, (T) == 2 ? 0 : 3) \
     } else {                                                                                              \
-        SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, (R) * 3 + (T), true, (3 * (R) + (T) + (P0)) & 1, 0, 3 * (R) + (T), 0, ((3 * (R) + (T) + (P0)) & 1) ^ 1, 0, FIRST, (T) == 2 ? 0 : 3) \
+        SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, P_GSLOT(R, P0) + (T), true, (3 * (R) + (T) + (P0)) & 1, 0, 3 * (R) + (T), 0, ((3 * (R) + (T) + (P0)) & 1) ^ 1, 0, FIRST, (T) == 2 ? 0 : 3) \
     }
 
     CSTAMP(0);
@@ -328,10 +331,10 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         auto issue_group = [&](int g) {
             const int gch = g / 3, gr = g - gch * 3;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) issue_w((ROWS ? t * 3 + gr : gr * 3 + t) * nch_tot + ch0 + gch, gr * 3 + t);   // ROWS: taps (ky = t, dx = gr)
+            for (int t = 0; t < 3; ++t) issue_w((ROWS ? t * 3 + gr : gr * 3 + t) * nch_tot + ch0 + gch, (g % NG) * 3 + t);   // ROWS: taps (ky = t, dx = gr)
         };
         issue_group(0);
-        if (ngroups > 1) issue_group(1);
+        if (NG == 3 && ngroups > 1) issue_group(1);
         // At the top of group g its slabs (requested two groups ago) must have landed; what this wave issued after them may
         // stay in flight: the slabs of group g+1 and, with two patch buffers, the next chunk's patch when that was
         // requested one group ago (at a chunk's first group).
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         const int g_ = (CH) * 3 + (R);                                                                    \
         const uint32_t pboff_ = DB ? ((CH) & 1) * G::PATCH : 0;   /* this chunk's patch buffer */          \
         CS_BEGIN                                                                                          \
-        if (g_ + 1 >= ngroups) wait_vmcnt<0>();                                                           \
+        if (NG == 2 || g_ + 1 >= ngroups) wait_vmcnt<0>();                                                \
         else if (DB && (R) == 1 && (CH) + 1 < nchunks) wait_vmcnt<3 * LPS + G::DPW>();                    \
         else wait_vmcnt<3 * LPS>();                                                                       \
         CS_MID                                                                                            \
@@ -350,20 +353,23 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
             /* one patch buffer, chunk boundary: every wave is past its last read of the old patch; refill it, run */ \
             /* the pending MFMAs of the previous tap underneath, then wait for the patch (older than the slabs) */ \
             issue_patch(CH);                                                                              \
-            if (g_ + 2 < ngroups && !CS_NODMA) issue_group(g_ + 2);                                       \
+            if (g_ + NG - 1 < ngroups && !CS_NODMA) issue_group(g_ + NG - 1);                                       \
             SPSP_MFMA_SET(((P0) & 1) ^ 1, ROWS ? ((P0) & 1) ^ 1 : ((P0) & 1) ^ 1, ROWS ? 2 : 0)           \
-            if (g_ + 2 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                            \
+            if (g_ + NG - 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                       \
             __builtin_amdgcn_s_barrier();                                                                 \
             SPSP_STEP(0, 0, P0, true)                                                                     \
         } else {                                                                                          \
             /* two patch buffers, first group of a chunk: every wave is past its reads of chunk CH-1, whose buffer */ \
             /* now takes chunk CH+1 -- it has the nine taps of this chunk to land (no wait at chunk boundaries)    */ \
             if (DB && (R) == 0 && (CH) + 1 < nchunks && !CS_NODMA) issue_patch((CH) + 1, ((CH) + 1) & 1); \
-            if (g_ + 2 < ngroups && !CS_NODMA) issue_group(g_ + 2);                                       \
+            if (g_ + NG - 1 < ngroups && !CS_NODMA) issue_group(g_ + NG - 1);                                       \
             SPSP_STEP(R, 0, P0, (R) == 0 && (CH) == 0)                                                    \
         }                                                                                                 \
+        if ((R) == 1 && (CH) == 0) { CSTAMP(10); }                                                        \
         SPSP_STEP(R, 1, P0, false)                                                                        \
+        if ((R) == 1 && (CH) == 0) { CSTAMP(11); }                                                        \
         SPSP_STEP(R, 2, P0, false)                                                                        \
+        if ((R) == 1 && (CH) == 0) { CSTAMP(12); }                                                        \
     }
         // ring slot of group g = 3 ch + r is r (three groups of three slabs); the register-set parity of a tap flips with ch
         for (int ch = 0; ch < nchunks; ch += 2) {
@@ -376,6 +382,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     if ((nsteps - 1) & 1) { if (ROWS && !((3 * nchunks - 1) & 1)) SPSP_MFMA_SET(1, 0, 2) else SPSP_MFMA_SET(1, 1, ROWS ? 2 : 0) }
     else { if (ROWS && ((3 * nchunks - 1) & 1)) SPSP_MFMA_SET(0, 1, 2) else SPSP_MFMA_SET(0, 0, ROWS ? 2 : 0) }
 #undef SPSP_STEP
+#undef P_GSLOT
 #undef SPSP_GTAP
 #undef P_WAIT
 #undef SPSP_MFMA_SET
@@ -477,13 +484,13 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     CS_WG(1)
 }
 
-template <bool W8, bool F16, bool DB, int NPG>
+template <bool W8, bool F16, bool DB, int NPG, int NG>
 int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, NPG>;
-    constexpr size_t lds = (size_t)9 * kWStage + (DB ? 2 : 1) * G::PATCH;
+    constexpr size_t lds = (size_t)3 * NG * kWStage + (DB ? 2 : 1) * G::PATCH;
     static_assert(lds <= 160 * 1024, "one CU has 160 KB of LDS");
     static_assert(lds >= (size_t)G::NW * 8192, "K-half exchange");
-    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG>>((int)lds)));
+    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG, NG>>((int)lds)));
     const int grid = (a.M / G::TPIX) * (a.N / 64);
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
@@ -494,15 +501,15 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         (void)hipMemset(b.dbg, 0, nd * sizeof(unsigned long long));
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG>), dim3(grid), dim3(64 * G::NW), (unsigned)lds, st, e0, e1, 0, b);
+        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG, NG>), dim3(grid), dim3(64 * G::NW), (unsigned)lds, st, e0, e1, 0, b);
         (void)hipDeviceSynchronize();
         float kms = 0.f;
         (void)hipEventElapsedTime(&kms, e0, e1);
         std::vector<unsigned long long> hv(nd);
         (void)hipMemcpy(hv.data(), b.dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         const unsigned long long* h = hv.data();
-        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d> chunks=%d wgs=%d: K loop %llu (of which weight wait %llu, barrier %llu) | residual loads + K-half exchange %llu | epilogue + stores %llu | total %llu cycles\n",
-                (int)W8, (int)DB, NPG, a.chunks, grid, h[4] - h[0], h[8], h[9], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d,NG=%d> chunks=%d wgs=%d: K loop %llu (of which weight wait %llu, barrier %llu) | residual loads + K-half exchange %llu | epilogue + stores %llu | total %llu cycles; one step (16 MFMAs) %llu, the next %llu\n",
+                (int)W8, (int)DB, NPG, NG, a.chunks, grid, h[4] - h[0], h[8], h[9], h[5] - h[4], h[6] - h[5], h[6] - h[0], h[11] - h[10], h[12] - h[11]);
         {
             unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
             double dur = 0;
@@ -520,14 +527,14 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG>, dim3(grid), dim3(64 * G::NW), lds, st, a);
+    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG, NG>, dim3(grid), dim3(64 * G::NW), lds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
 
-template <bool W8, bool DB, int NPG>
+template <bool W8, bool DB, int NPG, int NG>
 int launch(const ConvArgs& a, hipStream_t st) {
-    return a.f16 ? launch_t<W8, true, DB, NPG>(a, st) : launch_t<W8, false, DB, NPG>(a, st);
+    return a.f16 ? launch_t<W8, true, DB, NPG, NG>(a, st) : launch_t<W8, false, DB, NPG, NG>(a, st);
 }
 
 }  // namespace
@@ -556,19 +563,31 @@ int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels) {
     return best;      // 0: no split fits (the kernel falls back to channel-block-fastest over the whole grid)
 }
 
-int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, hipStream_t stream) {
+int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, int ring_groups, hipStream_t stream) {
     SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
     SPSP_REQUIRE(!a0.pool_out || a0.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
     SPSP_REQUIRE(tile_pixels == 256 || tile_pixels == 128, "conv_patch: tile of %d pixels", tile_pixels);
+    SPSP_REQUIRE(ring_groups == 2 || ring_groups == 3, "conv_patch: weight ring of %d groups", ring_groups);
     ConvArgs a = a0;
     a.xcd_n = conv_patch_xcd_n(a, tile_pixels);
-    const bool db = two_patch_buffers;
+    const bool db = two_patch_buffers, w8 = a.Wo == 8;
+    // (8 x 8 maps, 256-pixel tiles: two 50 KB patches do not fit beside a three-group ring -> one patch buffer)
+#define SPSP_PICK(W8, DB, NPG, NG) return launch<W8, DB, NPG, NG>(a, stream)
     if (tile_pixels == 256) {
-        if (a.Wo == 8) return launch<true, false, 4>(a, stream);        // (two 50 KB patches + the 72 KB ring do not fit)
-        return db ? launch<false, true, 4>(a, stream) : launch<false, false, 4>(a, stream);
+        if (ring_groups == 3) { if (w8) SPSP_PICK(true, false, 4, 3); if (db) SPSP_PICK(false, true, 4, 3); SPSP_PICK(false, false, 4, 3); }
+        if (w8) { if (db) SPSP_PICK(true, true, 4, 2); SPSP_PICK(true, false, 4, 2); }
+        if (db) SPSP_PICK(false, true, 4, 2);
+        SPSP_PICK(false, false, 4, 2);
     }
-    if (a.Wo == 8) return db ? launch<true, true, 2>(a, stream) : launch<true, false, 2>(a, stream);
-    return db ? launch<false, true, 2>(a, stream) : launch<false, false, 2>(a, stream);
+    if (ring_groups == 3) {
+        if (w8) { if (db) SPSP_PICK(true, true, 2, 3); SPSP_PICK(true, false, 2, 3); }
+        if (db) SPSP_PICK(false, true, 2, 3);
+        SPSP_PICK(false, false, 2, 3);
+    }
+    if (w8) { if (db) SPSP_PICK(true, true, 2, 2); SPSP_PICK(true, false, 2, 2); }
+    if (db) SPSP_PICK(false, true, 2, 2);
+    SPSP_PICK(false, false, 2, 2);
+#undef SPSP_PICK
 }
 
 }  // namespace spsp

@@ -260,6 +260,7 @@ struct spsp_regressor {
     RingTile ring[4];      // per residual stage: tile of the ring kernel (stride-2 / 1x1 convs; every conv of a ragged batch)
     bool patch_db[4];      // per residual stage: two patch buffers in the patch kernel
     int patch_tile[4];     // per residual stage: output pixels per patch-kernel tile (256: 8 waves, 128: 4 waves)
+    int patch_ring[4];     // per residual stage: depth of the patch kernel's weight ring, in groups of three slabs (2 or 3)
 };
 
 namespace {
@@ -296,7 +297,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
         ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
-        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], st);
+        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], st);
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
@@ -402,9 +403,11 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         const bool def_db[4] = {false, false, true, true};
         // 128-pixel tiles where 256-pixel ones cover half (layer3: 128) or a quarter (layer4: 64) of the 256 CUs
         const int def_tile[4] = {256, 256, 128, 128};
-        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; }
-#ifdef SPSP_TUNING
+        const int def_ring[4] = {3, 3, 3, 3};
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; }
+#if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
+        if (const char* e = getenv("SPSP_PATCH_RING")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_ring[0], &r->patch_ring[1], &r->patch_ring[2], &r->patch_ring[3]);
         if (const char* e = getenv("SPSP_PATCH_DB")) {
             int d[4] = {0, 0, 1, 1};
             (void)sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
