@@ -408,6 +408,11 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
 #if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
         if (const char* e = getenv("SPSP_PATCH_RING")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_ring[0], &r->patch_ring[1], &r->patch_ring[2], &r->patch_ring[3]);
+        if (const char* e = getenv("SPSP_RING_TILE")) {      // RingTile enum values: 0 128x128s3, 1 128x128s2, 2 128x64s3, 3 128x64s4, 4 64x128s3, 5 64x64s4
+            int d[4] = {2, 4, 4, 5};
+            (void)sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
+            for (int L = 0; L < 4; ++L) if (d[L] >= 0 && d[L] < (int)kRingNone) r->ring[L] = (RingTile)d[L];
+        }
         if (const char* e = getenv("SPSP_PATCH_DB")) {
             int d[4] = {0, 0, 1, 1};
             (void)sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
