@@ -275,12 +275,16 @@ class PlayerPipeline:
     underneath the MFMA-bound backbone of batch i+1.  Every batch still goes through the complete path; results
     are returned with the event that marks their completion."""
 
-    def __init__(self, make_regressor, make_smpl, device, depth=2, use_graphs=False):
+    def __init__(self, make_regressor, make_smpl, device, depth=2, use_graphs=False, streams=None):
+        """`streams`: run on these HIP streams (one per slot) instead of new ones -- a second pipeline of a process
+        should take over an idle pipeline's streams: past four active hardware queues the GPU time-slices them."""
         self.device = torch.device(device)
         self.use_graphs = bool(use_graphs)
         self.slots = []
-        for _ in range(depth):
-            st = torch.cuda.Stream(device=self.device)
+        if streams is not None and len(streams) != depth:
+            raise ValueError(f'{len(streams)} streams for {depth} slots')
+        for i in range(depth):
+            st = streams[i] if streams is not None else torch.cuda.Stream(device=self.device)
             self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
                                               smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False))
         self._next = 0

@@ -119,8 +119,10 @@ class RecordExchange:
             self.note = f' (spsp_comm set-up failed on a rank{": " + err if err else ""}; fell back)'
         self._rt = r
 
+    _xs = None          # the exchange's own stream (abi mode), created at the first all_gather
+
     def describe(self):
-        how = 'spsp_allgather_records (libspsp RCCL call on the slot stream)' if self.mode == 'abi' else 'torch.distributed.all_gather_into_tensor'
+        how = 'spsp_allgather_records (libspsp RCCL call on the exchange stream)' if self.mode == 'abi' else 'torch.distributed.all_gather_into_tensor'
         return how + self.note
 
     def all_gather(self, local, n_total):
@@ -136,10 +138,22 @@ class RecordExchange:
         if local.shape[0] < m:
             padded = torch.zeros((m, local.shape[1]), dtype=local.dtype, device=local.device)
             padded[:local.shape[0]] = local
-        out = torch.empty((self.world * m, local.shape[1]), dtype=local.dtype, device=local.device)
+        # The collective runs on this exchange's OWN stream, tied to the caller's stream by two events (what
+        # torch.distributed's process group does as well).  Issued directly on the pipeline's four slot streams, the ONE
+        # communicator orders its collectives across those streams and the slots stop overlapping: measured 72 k instead of
+        # 102 k players/s at world size 1.
+        cur = torch.cuda.current_stream(self.device)
+        if self._xs is None:
+            self._xs = torch.cuda.Stream(device=self.device)
+        xs = self._xs
+        out = torch.empty((self.world * m, local.shape[1]), dtype=local.dtype, device=local.device)   # on the caller's stream
+        xs.wait_stream(cur)
         r = self._rt
-        r.check(r.lib.spsp_allgather_records(r.ctx, self._comm, rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
-        padded.record_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(xs):
+            r.check(r.lib.spsp_allgather_records(r.ctx, self._comm, rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
+        padded.record_stream(xs)
+        out.record_stream(xs)
+        cur.wait_stream(xs)
         if all(s == m for s in sizes):
             return out
         return torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
