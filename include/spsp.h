@@ -166,7 +166,8 @@ int spsp_crop_players(spsp_ctx* ctx, const uint8_t* frame, int H, int W, const i
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
                            float* cam, float* pose6d, float* betas, float* feats, void* stream);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
- * (0 conv1+relu, 1 maxpool, 2..5 layer1..layer4) of the LAST forward as fp32 NCHW into `out`. */
+ * (1 maxpool, 2..5 layer1..layer4; stage 0 -- conv1+relu -- no longer exists as a map since conv1 and the max-pool are one
+ * kernel: SPSP_EINVAL) of the LAST forward as fp32 NCHW into `out`. */
 int spsp_regressor_read_stage(spsp_ctx* ctx, spsp_regressor* r, int stage, int B, float* out_nchw, void* stream);
 
 /* ---- small geometry ops ---------------------------------------------------------------------- */

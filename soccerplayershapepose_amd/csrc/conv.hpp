@@ -26,8 +26,8 @@ struct ConvArgs {
     int stride;
     int kw_steps, chunks, nsteps;
     int relu;
-    float* part;             // split-K: fp32 slabs [splitk][M][N] (conv_ring only)
-    int splitk;              // 1 = no split
+    float* part;             // unused since round 2 (split-K over workgroups is gone)
+    int splitk;              // 1; the stamped twin library uses -1 as a diagnosis switch (conv_patch.hip)
     unsigned int* counter;   // conv_wres: eight device words, 128 bytes apart, zero before the launch -- dynamic tile scheduler
     int f16;                 // element type of in / w / res / out: 0 = bf16, 1 = fp16 (conv_elem.hpp)
     int xcd_n;               // conv_patch: XCDs along the channel blocks (tile order; set by launch_conv_patch)

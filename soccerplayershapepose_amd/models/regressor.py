@@ -6,7 +6,7 @@
     cam, pose6d, shape = regressor(proxy_rep)                            # [B,18,256,256] fp32 NCHW
 
 Eval-mode BatchNorm is folded into the conv weights inside `spsp_regressor_load`; the forward is
-`spsp_regressor_forward` (csrc/regressor.hip, csrc/conv.hip)."""
+`spsp_regressor_forward` (csrc/regressor.hip, csrc/conv_*.hip)."""
 import ctypes as C
 import os
 
@@ -190,7 +190,8 @@ class SingleInputRegressor:
     __call__ = forward
 
     def read_stage(self, stage, B):
-        """Parity tap: stage 0 conv1+relu, 1 maxpool, 2..5 layer1..4 of the last forward, as fp32 NCHW."""
+        """Parity tap: stage 1 maxpool, 2..5 layer1..4 of the last forward, as fp32 NCHW (stage 0, conv1+relu, is never
+        materialised: conv1 and the max-pool are one kernel -> ValueError)."""
         S, Cc = [(128, 64), (64, 64), (64, 64), (32, 128), (16, 256), (8, 512)][stage]
         r = self._rt
         out = torch.empty((B, Cc, S, S), dtype=torch.float32, device=r.device)
