@@ -506,6 +506,29 @@ def test_regressor_native_input_batch_invariance_and_limits(regressor_gpu, dev):
         regressor_gpu(torch.zeros(2, 17, 256, 256, device=dev))
 
 
+def test_regressor_batch_72_equals_its_32_crop_blocks(regressor_sd_np, dev):
+    """More crops per call than the bench uses: 72 = two full blocks of 32 players + a ragged one for the fused IEF kernel
+    (one grid of 64 workgroups and one barrier counter per block), 288 layer1 tiles for 256 persistent workgroups, tile
+    counts that are no multiple of the XCD grid.  Every crop's result must be the one it gets in a batch of 32: the kernels
+    of both batch sizes add a pixel's products in the same order."""
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    B = 72
+    big = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(regressor_sd_np).to(dev)
+    ref = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=32, precision='f16').load_state_dict(regressor_sd_np).to(dev)
+    x, _ = S.proxy_crops(B, seed=21)
+    xt = torch.from_numpy(x).to(dev)
+    cam, pose, shape = big(xt)
+    assert torch.isfinite(cam).all() and torch.isfinite(pose).all() and torch.isfinite(shape).all()
+    for lo in (0, 32, 64):
+        hi = min(lo + 32, B)
+        c, p, s_ = ref(xt[lo:hi])
+        # ragged tail (8 crops): the 32-crop regressor then runs its ragged-batch kernels, summation order differs
+        tol = 0.0 if hi - lo == 32 else 2e-5
+        assert (cam[lo:hi] - c).abs().max().item() <= tol, (lo, (cam[lo:hi] - c).abs().max().item())
+        assert (pose[lo:hi] - p).abs().max().item() <= tol, (lo, (pose[lo:hi] - p).abs().max().item())
+        assert (shape[lo:hi] - s_).abs().max().item() <= tol, (lo, (shape[lo:hi] - s_).abs().max().item())
+
+
 # ---------------------------------------------------------------- end to end (a13)
 @pytest.mark.parametrize('precision', ['bf16', 'f16'])
 def test_end_to_end_against_oracle_pipeline(regressor_gpu, regressor_gpu_f16, smpl_gpu, oracle_smpl, regressor_sd_np, smpl_model_np, dev,
