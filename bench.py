@@ -474,6 +474,11 @@ def main():
                          'avg_us_timed_region': kernels.get(dom, {}).get('avg_us'),
                          'achieved_timed_region': achieved,
                          'all_convs_tflops': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12) if conv_us else None,
+                         'all_convs_frac': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS) if conv_us else None,
+                         # every kernel of the table that does the same work in each launch: isolated duration -> fraction of the peak
+                         'mfma_kernels': {k: {'launches_per_step': kernels_iso[k]['launches_per_step'], 'avg_us': round(kernels_iso[k]['avg_us'], 2),
+                                              'frac': round(f / (kernels_iso[k]['avg_us'] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                                          for k, f in cands.items() if k in kernels_iso},
                          'end_to_end_backbone_tflops': FLOP_BACKBONE * world * B * args.steps / elapsed / 1e12,
                          'end_to_end_backbone_frac': FLOP_BACKBONE * B * args.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS},
             'latency': {'workload': f'one {FRAME_PLAYERS}-player match frame (BASELINE configs[3]) through the whole path, nothing else in '
