@@ -281,7 +281,8 @@ def main():
     pipe = make_pipe(args.precision)
     reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl
     r = rt.get(dev)
-    exchange = RecordExchange(dev, mode=args.exchange) if use_dist else None
+    exchange = RecordExchange(dev, mode=args.exchange, lanes=len(pipe.slots)) if use_dist else None
+    lane_of = {id(sl.stream): i for i, sl in enumerate(pipe.slots)}      # a slot's stream -> its own communicator
 
     # ---- synthetic inputs (seed 1234 + rank), resident in HBM in the backbone-native layout ----
     x_nchw, joints_in = S.proxy_crops(B, seed=1234 + rank)
@@ -315,7 +316,8 @@ def main():
             res = pipe_.submit(inp, tgt, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
             if use_dist:
                 with torch.cuda.stream(res.stream):
-                    res.gathered = exchange.all_gather(res.record, world * B)
+                    # every slot's stream has its own communicator: the collective is the last thing in the slot's order
+                    res.gathered = exchange.all_gather(res.record, world * B, lane=lane_of.get(id(res.stream)))
             return res
         return step
 

@@ -256,7 +256,10 @@ def _with_wait(res):
     are marked as used by the caller's stream, so that the caching allocator does not hand their memory to the slot's
     next batch while a consumer kernel of the caller is still reading it.  (Done here and not in submit(): recording
     the stream makes every free of a result go through an event, which costs throughput when results are only
-    synchronised on, as in bench.py.)"""
+    synchronised on, as in bench.py.)
+    `res.hold_until(event)` (set by the pipeline) is the other direction: work on another stream that READS this result
+    (e.g. the record all-gather on the exchange's stream) registers its completion event, and the slot's next batch --
+    which rewrites the slot's buffers; with HIP graphs the very same addresses -- waits for it before it starts."""
     def wait(stream=None):
         st = stream if stream is not None else torch.cuda.current_stream(res.stream.device)
         st.wait_event(res.done)
@@ -286,7 +289,7 @@ class PlayerPipeline:
         for i in range(depth):
             st = streams[i] if streams is not None else torch.cuda.Stream(device=self.device)
             self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
-                                              smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False))
+                                              smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False, pending=[]))
         self._next = 0
 
     def submit(self, proxy_rep, joints2D, **kw):
@@ -298,6 +301,9 @@ class PlayerPipeline:
         self._next = (self._next + 1) % len(self.slots)
         caller = torch.cuda.current_stream(self.device)
         slot.stream.wait_stream(caller)                                     # inputs produced on the caller's stream
+        for ev in slot.pending:                                             # readers of the slot's previous results on other streams
+            slot.stream.wait_event(ev)                                      # (res.hold_until): the slot's buffers are about to be rewritten
+        slot.pending.clear()
         # The inputs were allocated on the caller's stream and are read on the slot's: tell the caching allocator, or a
         # buffer the caller drops right after submit() is handed to the caller's next allocation while this batch still
         # reads it.  The results are allocated on the slot's stream: consume them on another stream through res.wait().
@@ -311,6 +317,7 @@ class PlayerPipeline:
             res.done = torch.cuda.Event()
             res.done.record(slot.stream)
         res.stream = slot.stream
+        res.hold_until = slot.pending.append
         return _with_wait(res)
 
     def _submit_graph(self, slot, proxy_rep, joints2D, kw):
@@ -338,6 +345,7 @@ class PlayerPipeline:
             out.done = torch.cuda.Event()
             out.done.record(slot.stream)
         out.stream = slot.stream
+        out.hold_until = slot.pending.append
         return _with_wait(out)
 
     def synchronize(self):

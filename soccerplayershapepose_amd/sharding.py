@@ -5,6 +5,8 @@ independent unit, so crops shard in contiguous blocks with NO data-path collecti
 all-gather of the packed per-player record [cam(3) | R(216) | betas(10)] (916 B/player) after the fit --
 `torch.distributed` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  The message is tens of
 KB per rank: latency-bound, so it is ONE collective on equal-sized padded blocks, not a ring of small sends."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -73,7 +75,10 @@ class RecordExchange:
     rank, every rank falls back to `torch.distributed.all_gather_into_tensor` and `describe()` says so.
     mode 'torch': torch.distributed only (also what the gloo CPU tests use)."""
 
-    def __init__(self, device, mode='abi', group=None):
+    def __init__(self, device, mode='abi', group=None, lanes=1):
+        """lanes: communicators to create (abi mode).  A pipeline that issues its collectives from several streams gives
+        every stream its OWN communicator (`all_gather(..., lane=i)`): RCCL orders the collectives of one communicator
+        across the streams they are issued on, which chains the streams together."""
         self.device = torch.device(device)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -81,9 +86,16 @@ class RecordExchange:
         self.mode = mode
         self.note = ''
         self._comm = None
+        self._comms = []
         self._rt = None
         if mode == 'abi':
-            self._init_abi()
+            for _ in range(max(1, int(lanes))):
+                self._init_abi()
+                if self.mode != 'abi':
+                    break
+                self._comms.append(self._comm)
+            if self.mode == 'abi':
+                self._comm = self._comms[0]
 
     def _init_abi(self):
         import ctypes as C
@@ -122,13 +134,25 @@ class RecordExchange:
     _xs = None          # the exchange's own stream (abi mode), created at the first all_gather
 
     def describe(self):
-        how = 'spsp_allgather_records (libspsp RCCL call on the exchange stream)' if self.mode == 'abi' else 'torch.distributed.all_gather_into_tensor'
+        how = f'spsp_allgather_records (libspsp RCCL call, {len(self._comms)} communicator(s): one per pipeline stream)' if len(self._comms) > 1 else 'spsp_allgather_records (libspsp RCCL call on the exchange stream)' if self.mode == 'abi' else 'torch.distributed.all_gather_into_tensor'
         return how + self.note
 
-    def all_gather(self, local, n_total):
-        """local [n_local, 229] (this rank's shard, shard_range order) -> [n_total, 229] on every rank."""
+    def all_gather(self, local, n_total, wait=True, lane=None):
+        """local [n_local, 229] (this rank's shard, shard_range order) -> [n_total, 229] on every rank.
+        wait=True: the caller's current stream waits for the collective (the result can be used on it at once).
+        lane=i (abi mode, `lanes` > 1 at construction): run on communicator i ON THE CURRENT STREAM -- for a caller that
+        always uses lane i from the same stream.
+        wait=False: returns (gathered, event) and leaves the caller's stream alone -- a consumer does
+        `stream.wait_event(event)`; whoever owns `local` must not rewrite it before `event` (PlayerPipeline results:
+        `res.hold_until(event)`).  In the four-slot pipeline the blocking form costs 14 % of throughput: the slot's next
+        batch waits for a 30 KB copy that sits on a fifth hardware queue behind four saturated ones."""
         if self.mode != 'abi':
-            return all_gather_records(local, n_total, group=self.group, force_collective=True)
+            out = all_gather_records(local, n_total, group=self.group, force_collective=True)
+            if wait:
+                return out
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return out, ev
         from . import runtime as rt
         sizes = shard_sizes(n_total, self.world)
         if local.shape[0] != sizes[self.rank]:
@@ -142,6 +166,18 @@ class RecordExchange:
         # torch.distributed's process group does as well).  Issued directly on the pipeline's four slot streams, the ONE
         # communicator orders its collectives across those streams and the slots stop overlapping: measured 72 k instead of
         # 102 k players/s at world size 1.
+        if lane is not None:
+            # this stream's own communicator: the collective sits in the stream's order, nothing to wait for or hold
+            out = torch.empty((self.world * m, local.shape[1]), dtype=local.dtype, device=local.device)
+            r = self._rt
+            r.check(r.lib.spsp_allgather_records(r.ctx, self._comms[lane], rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
+            if not all(s == m for s in sizes):
+                out = torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
+            if wait:
+                return out
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return out, ev
         cur = torch.cuda.current_stream(self.device)
         if self._xs is None:
             self._xs = torch.cuda.Stream(device=self.device)
@@ -153,14 +189,28 @@ class RecordExchange:
             r.check(r.lib.spsp_allgather_records(r.ctx, self._comm, rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
         padded.record_stream(xs)
         out.record_stream(xs)
-        cur.wait_stream(xs)
-        if all(s == m for s in sizes):
-            return out
-        return torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
+        ev = None
+        if wait:
+            cur.wait_stream(xs)
+        else:
+            ev = torch.cuda.Event()
+            ev.record(xs)
+        if not all(s == m for s in sizes):
+            if wait:
+                out = torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
+            else:
+                with torch.cuda.stream(xs):
+                    out = torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
+                    out.record_stream(cur)
+                    ev.record(xs)
+        return out if wait else (out, ev)
 
     def close(self):
-        if self._comm is not None:
-            self._rt = self._rt or None
-            from . import runtime as rt
-            rt.get(self.device).lib.spsp_comm_destroy(self._comm)
-            self._comm = None
+        from . import runtime as rt
+        lib = rt.get(self.device).lib
+        seen = []
+        for c in list(self._comms) + [self._comm]:
+            if c is not None and not any(c is d for d in seen):
+                seen.append(c)
+                lib.spsp_comm_destroy(c)
+        self._comms, self._comm = [], None
