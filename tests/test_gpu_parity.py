@@ -889,6 +889,39 @@ def test_c_abi_rccl_allgather_of_records_single_rank(dev):
     assert p.returncode == 0 and 'rccl-ok' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+def test_record_exchange_lanes_and_nonblocking_form_single_rank(dev):
+    """`sharding.RecordExchange` as bench.py drives it (process group of one rank, in a child process): one communicator
+    per stream (`lanes`), the blocking and the event-returning form, ragged counts, and the exchange-stream form."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, torch, torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', RANK='0', WORLD_SIZE='1')
+        from soccerplayershapepose_amd.sharding import RecordExchange
+        dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        ex = RecordExchange(dev, mode='abi', lanes=3)
+        assert ex.mode == 'abi' and '3 communicator' in ex.describe(), ex.describe()
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        recs = [torch.randn(22, 229, device=dev) + i for i in range(3)]
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(4):
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    outs.append((i, ex.all_gather(recs[i], 22, lane=i)))
+        g, ev = ex.all_gather(recs[1], 22, wait=False)          # exchange-stream form, event instead of a wait
+        torch.cuda.current_stream().wait_event(ev)
+        g2 = ex.all_gather(recs[2], 22)                            # ... and its blocking form
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, recs[i]) for i, o in outs) and torch.equal(g, recs[1]) and torch.equal(g2, recs[2])
+        ex.close()
+        dist.destroy_process_group()
+        print('exchange-ok')
+    """)
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and 'exchange-ok' in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_handles_release_their_device_memory(regressor_sd_np, smpl_model_np, dev):
     """Loading and dropping handles repeatedly must give all device memory back (DevicePool frees on destroy)."""
     import gc
