@@ -22,6 +22,7 @@ import socket
 import subprocess
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -61,6 +62,14 @@ def parse(argv=None):
                     help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
     ap.add_argument('--rehearse-dist', action='store_true',
                     help='run the N>1 code path (RCCL communicators, per-step all-gather, barriers) even with one rank')
+    ap.add_argument('--inputs', type=int, default=0,
+                    help='distinct resident input batches rotated through the steps (0 = one per pipeline slot, at least 4): every step '
+                         'reads another 80 MB buffer, so the input is streamed from HBM and not re-read from the Infinity Cache')
+    ap.add_argument('--exchange-lanes', type=int, default=1,
+                    help='RCCL communicators of the exchange step.  1 (default): ONE communicator on the exchange\'s own stream, the '
+                         'slot\'s next batch held until the collective has read the record (no cross-stream ordering between ranks to '
+                         'get wrong).  N > 1: one communicator per pipeline stream, collectives issued on the slot streams -- measured '
+                         'at world size 1 only (DESIGN 6); concurrent communicators at N > 1 are opt-in until an N-GPU run has exercised them')
     ap.add_argument('--exchange', default='abi', choices=['abi', 'torch'],
                     help='N>1 exchange step: abi = spsp_allgather_records (the library\'s RCCL call on the slot stream), '
                          'torch = torch.distributed.all_gather_into_tensor')
@@ -103,6 +112,28 @@ def launch_ranks(args, argv):
     sys.stdout.write(lines[-1] + '\n')
     sys.stdout.flush()
     raise SystemExit(0)
+
+
+ROCPROF_ISOLATED = os.path.join('profiles', 'kernel_stats_regressor_only.csv')
+
+
+def rocprof_average_us(table_name):
+    """Average duration of the library kernel `table_name` (e.g. 'conv3x3_patch_kernel<false>') in the tracked rocprofv3
+    kernel trace of `tools/regressor_only.py 32 4 f16` (one batch in flight; profiles/README.md), or None.  The trace names
+    carry every template argument; the table name's arguments are a prefix of them."""
+    import csv
+    path = os.path.join(ROOT, ROCPROF_ISOLATED)
+    if not os.path.exists(path):
+        return None
+    base, _, targs = table_name.partition('<')
+    want = base + ('<' + targs.rstrip('>') if targs else '')
+    calls = tot = 0.0
+    for row in csv.DictReader(open(path)):
+        name = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        if name.startswith(want) and (not targs or name[len(want)] in ',>'):
+            calls += float(row['Calls'])
+            tot += float(row['TotalDurationUs'])
+    return tot / calls if calls else None
 
 
 def host_threads(requested):
@@ -281,24 +312,34 @@ def main():
     pipe = make_pipe(args.precision)
     reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl
     r = rt.get(dev)
-    exchange = RecordExchange(dev, mode=args.exchange, lanes=len(pipe.slots)) if use_dist else None
-    lane_of = {id(sl.stream): i for i, sl in enumerate(pipe.slots)}      # a slot's stream -> its own communicator
+    lanes = max(1, min(args.exchange_lanes, len(pipe.slots)))
+    exchange = RecordExchange(dev, mode=args.exchange, lanes=lanes) if use_dist else None
+    lane_of = {id(sl.stream): i % lanes for i, sl in enumerate(pipe.slots)}      # (lanes > 1) a slot's stream -> its communicator
 
-    # ---- synthetic inputs (seed 1234 + rank), resident in HBM in the backbone-native layout ----
-    x_nchw, joints_in = S.proxy_crops(B, seed=1234 + rank)
-    x_dev = torch.from_numpy(x_nchw).to(dev)
-    native = reg.pack(x_dev)
-    # fit targets: the regressor-initialised model, perturbed + 1 px noise; set-up, untimed
-    cam0, pose0, shape0 = reg(native)
-    R0 = rot6d_to_rotmat(pose0).view(B, 24, 3, 3)
-    pre_fit_vertices = smpl(full_pose=R0, betas=shape0).vertices.clone()
-    R2, b2, _ = S.pose_params(B, seed=77 + rank, body_deg=8, global_deg=10)
-    Rp = torch.matmul(torch.from_numpy(R2).to(dev), R0)
-    jp = smpl(body_pose=Rp[:, 1:], global_orient=Rp[:, :1], betas=shape0 + torch.from_numpy(b2).to(dev) / 3,
-              return_verts=False).joints
-    tgt_np = S.fit_targets_from_joints(jp.cpu().numpy(), cam0.cpu().numpy() * np.array([1.1, 1, 1], np.float32),
-                                       seed=4321 + rank)
-    tgt = torch.from_numpy(tgt_np[:, :, :2]).float().to(dev).contiguous()
+    # ---- synthetic inputs (seed 1234 + rank + 1000 * buffer), resident in HBM in the backbone-native layout.  SEVERAL
+    # distinct batches rotate through the steps (one per pipeline slot, at least 4: 4 x 80 MB > the 256 MB Infinity Cache),
+    # each with its own fit targets: regressor-initialised model, perturbed + 1 px noise; set-up, untimed ----
+    n_inputs = args.inputs if args.inputs > 0 else max(4, len(pipe.slots))
+
+    def make_input(k):
+        x_nchw_, joints_in_ = S.proxy_crops(B, seed=1234 + rank + 1000 * k)
+        x_dev_ = torch.from_numpy(x_nchw_).to(dev)
+        native_ = reg.pack(x_dev_)
+        cam0, pose0, shape0 = reg(native_)
+        R0 = rot6d_to_rotmat(pose0).view(B, 24, 3, 3)
+        pre_ = smpl(full_pose=R0, betas=shape0).vertices.clone()
+        R2, b2, _ = S.pose_params(B, seed=77 + rank + 1000 * k, body_deg=8, global_deg=10)
+        Rp = torch.matmul(torch.from_numpy(R2).to(dev), R0)
+        jp = smpl(body_pose=Rp[:, 1:], global_orient=Rp[:, :1], betas=shape0 + torch.from_numpy(b2).to(dev) / 3,
+                  return_verts=False).joints
+        tgt_np_ = S.fit_targets_from_joints(jp.cpu().numpy(), cam0.cpu().numpy() * np.array([1.1, 1, 1], np.float32),
+                                            seed=4321 + rank + 1000 * k)
+        tgt_ = torch.from_numpy(tgt_np_[:, :, :2]).float().to(dev).contiguous()
+        del x_dev_
+        return SimpleNamespace(k=k, x_nchw=x_nchw_, joints_in=joints_in_, native=native_, tgt=tgt_, tgt_np=tgt_np_, pre_fit_vertices=pre_)
+
+    inputs = [make_input(k) for k in range(n_inputs)]
+    x_nchw, joints_in, native, tgt = inputs[0].x_nchw, inputs[0].joints_in, inputs[0].native, inputs[0].tgt
     torch.cuda.synchronize()
 
     if args.from_detections:
@@ -308,20 +349,32 @@ def main():
         assert torch.equal(create_proxy_representation_batch(sil_dev, joints_dev, precision=args.precision).view(torch.int16),
                            native.view(torch.int16))
 
-    def make_step(pipe_, native_, precision):
+    def make_step(pipe_, natives_, precision):
+        state = SimpleNamespace(i=0)
+
         def step():
             # one batch through the WHOLE path on the next pipeline slot (its own stream): [proxy builder ->] regressor ->
-            # rot6d -> 50-iter fit -> SMPL forward [-> all-gather of the records]
-            inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=precision) if args.from_detections else native_
-            res = pipe_.submit(inp, tgt, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+            # rot6d -> 50-iter fit -> SMPL forward [-> all-gather of the records]; the input batch rotates
+            k = state.i % len(natives_)
+            state.i += 1
+            inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=precision) if args.from_detections else natives_[k]
+            res = pipe_.submit(inp, inputs[k].tgt, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+            res.input_index = k
             if use_dist:
                 with torch.cuda.stream(res.stream):
-                    # every slot's stream has its own communicator: the collective is the last thing in the slot's order
-                    res.gathered = exchange.all_gather(res.record, world * B, lane=lane_of.get(id(res.stream)))
+                    if lanes > 1:
+                        # opt-in: the slot's stream has its own communicator, the collective is the last thing in the slot's order
+                        res.gathered = exchange.all_gather(res.record, world * B, lane=lane_of.get(id(res.stream)))
+                    else:
+                        # ONE communicator on the exchange's stream: every rank issues its collectives in the same (program) order;
+                        # the slot's next batch waits until this one's record has been read
+                        res.gathered, ev = exchange.all_gather(res.record, world * B, wait=False)
+                        res.hold_until(ev)
             return res
+        step.state = state
         return step
 
-    step = make_step(pipe, native, args.precision)
+    step = make_step(pipe, [d.native for d in inputs], args.precision)
 
     def barrier():
         if use_dist:
@@ -347,7 +400,7 @@ def main():
     # ---- untimed per-kernel pass: every kernel bracketed by a HIP-event pair on its launch stream, ONE batch in
     # flight (slot 0, a sync after every step), so a launch's duration is free of the cross-batch sharing the
     # pipelined timed region has by design (and agrees with the rocprofv3 average of the same command)
-    iso_steps = 8
+    iso_steps = 2 * n_inputs
     r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
     r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
     for _ in range(iso_steps):
@@ -373,7 +426,8 @@ def main():
         if args.graphs:
             # each slot's step is captured into a HIP graph (untimed) and replayed; events are not recorded inside graphs
             pipe_.use_graphs = True
-            for _ in range(len(pipe_.slots)):
+            import math
+            for _ in range(math.lcm(len(pipe_.slots), n_inputs)):      # every (slot, input batch) pair that will occur
                 step_fn()
             torch.cuda.synchronize()
         elif select_id is not None:
@@ -400,6 +454,7 @@ def main():
     assert torch.isfinite(out.vertices).all() and out.vertices.abs().max().item() > 0.1
     kernels = read_profile(args.steps)
     post_fit_vertices = out.vertices.clone()
+    parity_input = inputs[out.input_index]
     if args.graphs:
         # Events cannot be read back from inside a replayed graph, so the timed region above carries no event pair.  The same
         # pipeline is therefore run a little longer EAGERLY (same slots, same streams, four batches in flight; not part of
@@ -451,10 +506,10 @@ def main():
         # four active queues the GPU time-slices them (the second figure then read 25 % low)
         pipe2 = make_pipe(alt_prec, streams=[sl.stream for sl in pipe.slots])
         reg2 = pipe2.slots[0].regressor
-        native2 = reg2.pack(x_dev)
-        c2, p2, s2 = reg2(native2)
+        natives2 = [reg2.pack(torch.from_numpy(d.x_nchw).to(dev)) for d in inputs]
+        c2, p2, s2 = reg2(natives2[0])
         pre2 = smpl(full_pose=rot6d_to_rotmat(p2).view(B, 24, 3, 3), betas=s2).vertices.clone()
-        step2 = make_step(pipe2, native2, alt_prec)
+        step2 = make_step(pipe2, natives2, alt_prec)
         for _ in range(args.warmup):
             step2()
         torch.cuda.synchronize()
@@ -480,7 +535,7 @@ def main():
                                    f'(6890 verts, 90 joints)' + (' -> RCCL all-gather of [cam|R|betas]' if use_dist else ''),
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
-                       'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs),
+                       'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs), 'input_batches_rotated': n_inputs,
                        'proxy_built_on_gpu': bool(args.from_detections),
                        'exchange': (exchange.describe() if exchange else None)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
@@ -509,24 +564,40 @@ def main():
             'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},
         }
+        # cross-check against the TRACKED rocprofv3 kernel trace of the isolated command (same build): the live figure must be
+        # reproducible from a file under profiles/
+        rp = rocprof_average_us(dom) if args.precision == 'f16' and B == BATCH_PER_GPU else None
+        if rp is not None:
+            line['roofline']['rocprof'] = {'source': ROCPROF_ISOLATED + ' (rocprofv3 --kernel-trace --stats -- python3 tools/regressor_only.py 32 4 f16)',
+                                           'avg_us': rp, 'frac': cands[dom] / (rp * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                                           'live_over_rocprof': kernels_iso[dom]['avg_us'] / rp}
         if alt is not None:
             line['alt_precision'] = {'dtype': alt['dtype'], 'value': alt['value'], 'unit': 'players/s', 'ms_per_step': alt['ms_per_step']}
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads(args.cpu_threads)
-            base, parity = cpu_baseline(sd, model, torch.from_numpy(x_nchw), tgt_np, args.cpu_fit_sample, threads,
-                                        pre_fit_vertices, post_fit_vertices)
+            base, parity = cpu_baseline(sd, model, torch.from_numpy(parity_input.x_nchw), parity_input.tgt_np, args.cpu_fit_sample, threads,
+                                        parity_input.pre_fit_vertices, post_fit_vertices)
             line['cpu_baseline'] = base
-            line['parity'] = dict(parity, dtype=args.precision)
+            # the north-star tolerance (vertices within 1e-3 m of the CPU reference path) is a pass / fail property of the line
+            parity['ok'] = bool(parity['pre_fit_max_m'] <= parity['tolerance_m'] and parity['post_fit_max_m'] <= parity['tolerance_m'])
+            line['parity'] = dict(parity, dtype=args.precision, input_batch=int(parity_input.k))
             if alt is not None:
                 _, parity2 = cpu_baseline_parity_only(sd, model, torch.from_numpy(x_nchw), alt['pre_fit_vertices'])
                 line['alt_precision']['parity'] = parity2
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + '\n').encode())
+        parity_failed = 'parity' in line and not line['parity']['ok']
+    else:
+        parity_failed = False
     if use_dist:
         dist.barrier()
         if exchange:
             exchange.close()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.stderr.write(f'bench.py: PARITY FAILED -- vertices deviate from the all-fp32 CPU reference path by more than '
+                         f'{line["parity"]["tolerance_m"]} m ({line["parity"]}); the line above is not a valid result\n')
+        raise SystemExit(3)
 
 
 def cpu_baseline_parity_only(sd, model, x_nchw, gpu_pre):

@@ -130,6 +130,13 @@ const char* spsp_conv_bn_name(int i);
  *                which the END-TO-END vertices stay within 1e-3 m of the all-fp32 reference path. */
 #define SPSP_PRECISION_BF16 0
 #define SPSP_PRECISION_F16  1
+/* max_batch <= SPSP_REGRESSOR_MAX_BATCH players per forward (the fused IEF kernel holds eight blocks of 32; larger sets:
+ * several calls).  At most SPSP_REGRESSOR_MAX_CONCURRENT forwards (of any handles) may be in flight on a device at once:
+ * the fused IEF's workgroups wait for each other, and that many launches can always make progress (checked at load
+ * against the device's occupancy).  Beyond it a hand-off may starve; it then times out, the outputs are NaN and the
+ * next call on the handle -- or spsp_regressor_status -- returns SPSP_EHIP. */
+#define SPSP_REGRESSOR_MAX_BATCH      256
+#define SPSP_REGRESSOR_MAX_CONCURRENT 8
 int  spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_batch, int precision,
                          spsp_regressor** out);
 void spsp_regressor_free(spsp_regressor* r);
@@ -165,6 +172,14 @@ int spsp_crop_players(spsp_ctx* ctx, const uint8_t* frame, int H, int W, const i
 /* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
                            float* cam, float* pose6d, float* betas, float* feats, void* stream);
+/* SPSP_OK, or SPSP_EHIP when a kernel of an earlier forward on this handle reported a device-side failure (the fused
+ * IEF's bounded hand-off wait).  Reads a host-visible status word: no synchronisation, callable at any time -- e.g. after a
+ * HIP-graph replay, which makes no library call that could report it.  Reading clears the status. */
+int spsp_regressor_status(spsp_regressor* r);
+/* Test hooks.  SPSP_DEBUG_IEF_STALL (value != 0): the NEXT forward launches its IEF one workgroup short of what its
+ * hand-offs wait for, with a short spin bound -- exercises the time-out report without hanging anything. */
+#define SPSP_DEBUG_IEF_STALL 1
+int spsp_regressor_debug(spsp_regressor* r, int what, int value);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
  * (1 maxpool, 2..5 layer1..layer4; stage 0 -- conv1+relu -- no longer exists as a map since conv1 and the max-pool are one
  * kernel: SPSP_EINVAL) of the LAST forward as fp32 NCHW into `out`. */

@@ -24,6 +24,8 @@ OK, EINVAL, ENOMEM, EHIP, ENCCL = 0, -1, -2, -3, -4           # include/spsp.h s
 PROXY_NCHW_F32, PROXY_NATIVE = 0, 1
 PRECISION_BF16, PRECISION_F16 = 0, 1
 SIL_U8, SIL_F32 = 0, 1
+DEBUG_IEF_STALL = 1
+REGRESSOR_MAX_BATCH, REGRESSOR_MAX_CONCURRENT = 256, 8
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -138,6 +140,8 @@ _PROTOS = {
     'spsp_crop_players': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spsp_regressor_read_stage': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    'spsp_regressor_status': (C.c_int, [_vp]),
+    'spsp_regressor_debug': (C.c_int, [_vp, C.c_int, C.c_int]),
     'spsp_rot6d_to_rotmat': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     'spsp_project': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
     'spsp_wp_to_translation': (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float, _vp, _vp]),

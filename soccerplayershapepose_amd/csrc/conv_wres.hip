@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int t = __builtin_amdgcn_readfirstlane(s_tile[2]);
-    if (t >= ntiles) return;
+    if ((unsigned)t >= (unsigned)ntiles) return;
     if (tid < 64) reinterpret_cast<float*>(smem + kBiasOff)[tid] = a.bias[wres_channel(tid >> 4, tid & 15)];                                // a late starter: the resident workgroups took every tile
 
     // ---- all nine weight slabs, once: piece p = 8 LDS rows of one tap; lane l -> LDS row R = 8 (p & 7) + l/8 (which
@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave has left the other buffer
         if (ntile_done == 0) { WSTAMP(1); } else if (ntile_done == 1) { WSTAMP(4); }
         const int tn = __builtin_amdgcn_readfirstlane(s_tile[BUF]);
-        if (tn < ntiles) issue_patch(tn, patch + (BUF ^ 1) * kPatch);
+        // (unsigned compares: a negative or garbage id -- a stale register, see below -- must never become an address)
+        const bool tn_ok = (unsigned)tn < (unsigned)ntiles;
+        if (tn_ok) issue_patch(tn, patch + (BUF ^ 1) * kPatch);
         {
             // Next id: a returning atomic whose result is not needed for a whole tile.  Inline asm, because hipcc's own
             // atomic waits for the return at once (wave-aggregated lowering, or a copy of the result), which would park the
@@ -257,7 +259,10 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
             // the data has arrived (it did: a stale tile id, found as a memory fault at 512 tiles) -- so the result goes
             // to an AGPR, which the register allocator has no reason to touch before the asm above reads it, and the
             // statement has no branch around it (lane 0 of wave 0 is selected through EXEC; EXEC = 0 issues nothing).
-            const int only = __builtin_amdgcn_readfirstlane((wave == 0 && tn < ntiles) ? 1 : 0);
+            // "No reason to" is not a guarantee: tests/test_abi_and_host.py disassembles this kernel and fails if any
+            // instruction between the atomic and the `s_waitcnt vmcnt(0); v_accvgpr_read` names that AGPR, and every use of
+            // an id is range-checked unsigned, so that a stale id could cost a wrong tile, never a wild address.
+            const int only = __builtin_amdgcn_readfirstlane((wave == 0 && tn_ok) ? 1 : 0);
             const unsigned one = 1u;
             unsigned long long saved;
             asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\t"
@@ -310,13 +315,13 @@ __global__ __launch_bounds__(256) void conv3x3_wres_kernel(const ConvArgs a) {
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     tile(B0{}, std::false_type{}, accA, accB);              // the first tile has no predecessor to store
-    if (t >= ntiles) flush(accA);
+    if ((unsigned)t >= (unsigned)ntiles) flush(accA);
     else
         for (;;) {
             tile(B1{}, std::true_type{}, accB, accA);
-            if (t >= ntiles) { flush(accB); break; }
+            if ((unsigned)t >= (unsigned)ntiles) { flush(accB); break; }
             tile(B0{}, std::true_type{}, accA, accB);
-            if (t >= ntiles) { flush(accA); break; }
+            if ((unsigned)t >= (unsigned)ntiles) { flush(accA); break; }
         }
 #undef WRES_STEP
 #undef WRES_M2

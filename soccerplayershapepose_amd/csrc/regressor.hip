@@ -111,10 +111,12 @@ struct IefArgs {
     float *h1, *s;                              // [B][512] each: written and re-read across workgroups (never const/restrict)
     float *cam, *pose, *betas;
     unsigned int* counters;                     // one monotonic arrival counter per block of 32 players
+    unsigned int* err;                          // host-visible status word of the handle: a hand-off that timed out sets bit 0
+    unsigned int spin_limit;                    // polls of one hand-off before it gives up
     int B, iters;
 };
 
-__device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned int target) {
+__device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned int target, unsigned int spin_limit) {
     __shared__ int ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its stores have left
     __syncthreads();
@@ -126,7 +128,7 @@ __device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned
         int good = 1;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) { good = 0; break; }        // ~ seconds: a workgroup never became resident
+            if (++spins > spin_limit) { good = 0; break; }        // 2^22: ~ seconds -- a workgroup never became resident
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -200,20 +202,23 @@ __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
 
     const float f1 = ief_product(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s);
     if (live) a.h1[(size_t)b * kHid + n] = fmaxf(f1 + a.cvec[n], 0.f);
-    bool ok = ief_grid_barrier(counter, kIefG * ++phase);
+    bool ok = ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
     float ssum = 0.f;
     const float b2 = a.b2[n];
     for (int it = 0; it < a.iters; ++it) {
         if (it > 0) {
             const float v = ief_product(ief_w + 4096, a.s + (size_t)rA * kHid, a.s + (size_t)rB * kHid, s);
             if (live) a.h1[(size_t)b * kHid + n] = fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f);
-            ok &= ief_grid_barrier(counter, kIefG * ++phase);
+            ok &= ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
         }
         const float v = ief_product(ief_w + 2 * 4096, a.h1 + (size_t)rA * kHid, a.h1 + (size_t)rB * kHid, s);
         ssum += fmaxf(b2 + v, 0.f);
         if (live) a.s[(size_t)b * kHid + n] = ssum;
-        ok &= ief_grid_barrier(counter, kIefG * ++phase);
+        ok &= ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
     }
+    // A hand-off that gave up: the outputs become NaN (nothing downstream can mistake them for a result) AND the handle's
+    // host-visible status word is set, so that the next call on the handle returns SPSP_EHIP (spsp_regressor_status).
+    if (!ok && t == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (8 * g < kNPar) {
         float v = a.p0[n < kNPar ? n : 0] + ief_product(ief_w + 3 * 4096, a.s + (size_t)rA * kHid, a.s + (size_t)rB * kHid, s);
         if (!ok) v = __builtin_nanf("");
@@ -261,6 +266,11 @@ struct spsp_regressor {
     bool patch_db[4];      // per residual stage: two patch buffers in the patch kernel
     int patch_tile[4];     // per residual stage: output pixels per patch-kernel tile (256: 8 waves, 128: 4 waves)
     int patch_ring[4];     // per residual stage: depth of the patch kernel's weight ring, in groups of three slabs (2 or 3)
+    unsigned int* err_host = nullptr;   // pinned, mapped, coherent host word: device-side failures of this handle's kernels (bit 0: IEF hand-off time-out)
+    unsigned int* err_dev = nullptr;    // the same word as the kernels see it
+    int ief_capacity = 0;               // IEF workgroups the device can hold at once (occupancy x CUs)
+    int debug_ief_stall = 0;            // test hook (spsp_regressor_debug): the next forward's IEF cannot complete its hand-offs
+    ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
 
 namespace {
@@ -322,6 +332,8 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     SPSP_REQUIRE(ctx && w && out && max_batch > 0, "spsp_regressor_load: bad arguments");
     SPSP_REQUIRE(precision == 0 || precision == 1, "spsp_regressor_load: precision %d (0 = bf16 MFMA, 1 = fp16 MFMA)", precision);
     SPSP_REQUIRE(w->ief_iters >= 0 && w->ief_iters <= 16, "spsp_regressor_load: ief_iters=%d", w->ief_iters);
+    // the fused IEF holds eight blocks of 32 players per launch (one barrier counter line each)
+    SPSP_REQUIRE(max_batch <= SPSP_REGRESSOR_MAX_BATCH, "spsp_regressor_load: max_batch=%d exceeds %d players per call", max_batch, SPSP_REGRESSOR_MAX_BATCH);
     for (int i = 0; i < SPSP_NUM_CONVS; ++i)
         SPSP_REQUIRE(w->conv[i].weight && w->conv[i].bn_weight && w->conv[i].bn_bias && w->conv[i].bn_mean && w->conv[i].bn_var,
                      "spsp_regressor_load: NULL array for %s", kConvs[i].name);
@@ -395,6 +407,32 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         for (int j = 0; j < 3; ++j)
             TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
     TRY(r->pool.alloc(&r->counters, kCounterWords, true));
+    {   // status word the kernels can raise and the host can read without a synchronisation
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { delete r; set_error("spsp_regressor_load: hipHostMalloc(status word) failed"); return SPSP_ENOMEM; }
+        r->err_host = static_cast<unsigned int*>(hp);
+        std::memset(hp, 0, 64);
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { delete r; set_error("spsp_regressor_load: hipHostGetDevicePointer failed"); return SPSP_EHIP; }
+        r->err_dev = static_cast<unsigned int*>(dp);
+    }
+    {   // The fused IEF spins on grid-wide hand-offs under an ordinary launch, so the 64 workgroups of a block of 32 players
+        // must be able to be resident TOGETHER.  Every other kernel of the path runs to completion without waiting on
+        // anything, and a launch's workgroups are dispatched in order, so at most ONE unit per concurrent IEF launch is
+        // ever partly resident; progress is guaranteed while (concurrent forwards) x 64 fits into what the device holds:
+        // occupancy x CUs (2 per CU at 64 KB of LDS: 512 on MI355X = 8 concurrent forwards).  Checked here, documented in
+        // spsp.h; a hand-off that still starves times out and is reported (spsp_regressor_status).
+        TRY(ensure_dynamic_lds<&ief_fused_kernel>(kIefLds));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ief_fused_kernel, 256, kIefLds) != hipSuccess) per_cu = 0;
+        r->ief_capacity = per_cu * ctx->num_cus;
+        if (w->ief_iters > 0 && r->ief_capacity < kIefG * SPSP_REGRESSOR_MAX_CONCURRENT) {
+            const int cap = r->ief_capacity;
+            delete r;
+            set_error("spsp_regressor_load: the device holds %d IEF workgroups at once, %d concurrent forwards need %d", cap, SPSP_REGRESSOR_MAX_CONCURRENT, kIefG * SPSP_REGRESSOR_MAX_CONCURRENT);
+            return SPSP_EINVAL;
+        }
+    }
     {   // plan of the residual stages (ONE plan; measured at 32 crops)
         const RingTile def_t[4] = {kRing128x64s3, kRing64x128s3, kRing64x128s3, kRing64x64s4};
         // two patch buffers where the layer has fewer tiles than the chip has CUs (layer3, layer4); layer2 fills every
@@ -446,6 +484,7 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
                            float* pose6d, float* betas, float* feats, void* stream) {
     SPSP_REQUIRE(ctx && r, "spsp_regressor_forward: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
+    SPSP_TRY(spsp_regressor_status(r));             // a device-side failure of an earlier forward surfaces on the next call
     if (B == 0) return SPSP_OK;
     SPSP_REQUIRE(proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
     SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_forward: B=%d exceeds max_batch=%d", B, r->max_batch);
@@ -503,16 +542,23 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
     // IEF (ief_module.py:48-64): params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) } -- one launch
     if (r->ief_iters > 0) {
         const int npb = (B + 31) / 32;
-        SPSP_REQUIRE(npb <= 8, "spsp_regressor_forward: the fused IEF holds at most 256 players per call");
         IefArgs ia;
         ia.feats = r->feats; ia.w1f = r->w1f; ia.w13 = r->w13; ia.w2 = r->w2; ia.w3 = r->w3;
         ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
         ia.h1 = r->h1; ia.s = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
         ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed above)
         ia.B = B; ia.iters = r->ief_iters;
+        ia.err = r->err_dev;
+        ia.spin_limit = 1u << 22;
+        int ief_wgs = kIefG;
+        if (r->debug_ief_stall) {       // test hook: one workgroup short of what the hand-offs wait for, and a short fuse
+            r->debug_ief_stall = 0;
+            ief_wgs = kIefG - 1;
+            ia.spin_limit = 1u << 9;
+        }
         SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel>(kIefLds));
         ProfScope ps(ctx, kKIefFc, st, true);
-        launch_kernel(&ief_fused_kernel, dim3(kIefG, npb), dim3(256), kIefLds, st, ia);
+        launch_kernel(&ief_fused_kernel, dim3(ief_wgs, npb), dim3(256), kIefLds, st, ia);
     } else {
         ProfScope ps(ctx, kKIefMisc, st);
         ief_init_only_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, cam, pose6d, betas);
@@ -520,6 +566,24 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
     SPSP_HIP_CHECK(hipGetLastError());
     if (feats) SPSP_HIP_CHECK(hipMemcpyAsync(feats, r->feats, (size_t)B * kFeat * sizeof(float), hipMemcpyDeviceToDevice, st));
 #undef TRY
+    return SPSP_OK;
+}
+
+int spsp_regressor_status(spsp_regressor* r) {
+    SPSP_REQUIRE(r, "spsp_regressor_status: NULL handle");
+    if (!r->err_host) return SPSP_OK;
+    const unsigned int e = __atomic_exchange_n(r->err_host, 0u, __ATOMIC_ACQ_REL);
+    if (e == 0) return SPSP_OK;
+    set_error("spsp_regressor: a grid-wide hand-off of the fused IEF kernel timed out in an earlier forward on this handle (status %u): "
+              "its cam / pose6d / betas are NaN.  More concurrent forwards than the device can hold IEF units for (%d workgroups)?",
+              e, r->ief_capacity);
+    return SPSP_EHIP;
+}
+
+int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
+    SPSP_REQUIRE(r, "spsp_regressor_debug: NULL handle");
+    SPSP_REQUIRE(what == SPSP_DEBUG_IEF_STALL, "spsp_regressor_debug: unknown hook %d", what);
+    r->debug_ief_stall = value != 0;
     return SPSP_OK;
 }
 

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(1024) void raster_kernel(const float* __restrict__ 
     const int lane = tid & 63;
     // the coverage test of one sample against one face (the reference's arithmetic, see the header); sets the bit
     auto test_sample = [&](int xi, int yi, float x0, float y0, float x1, float y1, float x2, float y2, float z0, float z1, float z2) {
+#pragma clang fp contract(off)      // the restated renderer rounds every product: no fused multiply-add in the coverage / depth tests
         const float yp = (2.f * (float)yi + 1.f - fis) / fis, xp = (2.f * (float)xi + 1.f - fis) / fis;
         const float e0x = x1 - x0, e0y = y1 - y0, e1x = x2 - x1, e1y = y2 - y1, e2x = x0 - x2, e2y = y0 - y2;
         const float l0 = (yp - y0) * e0x, r0 = (xp - x0) * e0y;

@@ -161,6 +161,13 @@ class SingleInputRegressor:
     def handle(self):
         return self._handle
 
+    def check_status(self):
+        """Raises RuntimeError if a kernel of an earlier forward on this handle reported a device-side failure (the fused
+        IEF's bounded hand-off wait; its outputs are NaN).  No synchronisation: a host-visible status word is read.  Every
+        forward checks it on entry; callers that replay a captured HIP graph (no library call) check it themselves."""
+        if self._handle is not None:
+            self._rt.check(self._rt.lib.spsp_regressor_status(self._handle), 'spsp_regressor_status')
+
     def forward(self, input, return_feats=False):
         native = isinstance(input, torch.Tensor) and input.dtype in (torch.bfloat16, torch.float16)
         if native and input.dtype != self.native_dtype:

@@ -340,6 +340,7 @@ class PlayerPipeline:
                 # the inputs are kept alive with the graph that reads them
                 entry = slot.graphs[key] = (g, res, proxy_rep, joints2D)
             g, res = entry[0], entry[1]
+            slot.regressor.check_status()        # a replay makes no library call: device-side failures of earlier batches surface here
             g.replay()
             out = SimpleNamespace(**vars(res))
             out.done = torch.cuda.Event()

@@ -97,39 +97,59 @@ class RecordExchange:
             if self.mode == 'abi':
                 self._comm = self._comms[0]
 
-    def _init_abi(self):
+    # The two library calls of the set-up, separately overridable (the world-size-2 gloo test stubs them on the CPU).
+    def _draw_unique_id(self):
+        """rank 0: (128 id bytes, '') or (None, error text)"""
         import ctypes as C
         from . import runtime as rt
         r = rt.get(self.device)
-        ident = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        buf = (C.c_ubyte * 128)()
+        if r.lib.spsp_comm_unique_id(buf) != 0:
+            return None, r.lib.spsp_last_error().decode('utf-8', 'replace')
+        return bytes(bytearray(buf)), ''
+
+    def _init_rank(self, id_bytes):
+        """every rank (collective: blocks until all ranks have called it): (communicator handle, '') or (None, error text)"""
+        import ctypes as C
+        from . import runtime as rt
+        r = rt.get(self.device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = r.lib.spsp_comm_init_rank(r.ctx, id_bytes, self.world, self.rank, C.byref(h))
+        if rc != 0:
+            return None, r.lib.spsp_last_error().decode('utf-8', 'replace')
+        return h, ''
+
+    def _init_abi(self):
+        """Collective.  The id travels with an OK flag (byte 128 of the broadcast): if rank 0 could not draw one, EVERY rank
+        skips the blocking `spsp_comm_init_rank` and falls back together -- with the failure recorded on rank 0 alone the
+        others would enter ncclCommInitRank and wait for a rank that never comes.  A second agreement (MIN all-reduce)
+        follows the init itself."""
+        ident = torch.zeros(129, dtype=torch.uint8, device=self.device)
         err = ''
         if self.rank == 0:
-            buf = (C.c_ubyte * 128)()
-            rc = r.lib.spsp_comm_unique_id(buf)
-            if rc != 0:
-                err = r.lib.spsp_last_error().decode('utf-8', 'replace')
-            else:
-                ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            raw, err = self._draw_unique_id()
+            if raw is not None:
+                ident[:128] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+                ident[128] = 1
         if dist.is_initialized():
             dist.broadcast(ident, src=0, group=self.group)
-        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.device)
-        if not err:
-            host = bytes(ident.cpu().numpy().tobytes())
-            h = C.c_void_p()
-            with torch.cuda.device(self.device):
-                rc = r.lib.spsp_comm_init_rank(r.ctx, host, self.world, self.rank, C.byref(h))
-            if rc != 0:
-                err = r.lib.spsp_last_error().decode('utf-8', 'replace')
+        have_id = int(ident[128].item()) == 1
+        ok = torch.tensor([1 if have_id else 0], dtype=torch.int32, device=self.device)
+        if have_id:
+            h, err = self._init_rank(bytes(ident[:128].cpu().numpy().tobytes()))
+            if h is None:
                 ok.zero_()
             else:
                 self._comm = h
-        if dist.is_initialized():
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if dist.is_initialized():
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) == 0:          # collective decision: nobody uses a half-built communicator
             self.close()
             self.mode = 'torch'
-            self.note = f' (spsp_comm set-up failed on a rank{": " + err if err else ""}; fell back)'
-        self._rt = r
+            what = 'spsp_comm_unique_id failed on rank 0' if not have_id else 'spsp_comm_init_rank failed on a rank'
+            self.note = f' ({what}{": " + err if err else ""}; every rank fell back to torch.distributed)'
+
 
     _xs = None          # the exchange's own stream (abi mode), created at the first all_gather
 
@@ -169,7 +189,7 @@ class RecordExchange:
         if lane is not None:
             # this stream's own communicator: the collective sits in the stream's order, nothing to wait for or hold
             out = torch.empty((self.world * m, local.shape[1]), dtype=local.dtype, device=local.device)
-            r = self._rt
+            r = rt.get(self.device)
             r.check(r.lib.spsp_allgather_records(r.ctx, self._comms[lane], rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
             if not all(s == m for s in sizes):
                 out = torch.cat([out[i * m:i * m + s] for i, s in enumerate(sizes)], dim=0)
@@ -184,7 +204,7 @@ class RecordExchange:
         xs = self._xs
         out = torch.empty((self.world * m, local.shape[1]), dtype=local.dtype, device=local.device)   # on the caller's stream
         xs.wait_stream(cur)
-        r = self._rt
+        r = rt.get(self.device)
         with torch.cuda.stream(xs):
             r.check(r.lib.spsp_allgather_records(r.ctx, self._comm, rt.ptr(padded), m, rt.ptr(out), r.stream()), 'spsp_allgather_records')
         padded.record_stream(xs)
@@ -205,12 +225,14 @@ class RecordExchange:
                     ev.record(xs)
         return out if wait else (out, ev)
 
-    def close(self):
+    def _destroy(self, comm):
         from . import runtime as rt
-        lib = rt.get(self.device).lib
+        rt.get(self.device).lib.spsp_comm_destroy(comm)
+
+    def close(self):
         seen = []
         for c in list(self._comms) + [self._comm]:
             if c is not None and not any(c is d for d in seen):
                 seen.append(c)
-                lib.spsp_comm_destroy(c)
+                self._destroy(c)
         self._comms, self._comm = [], None

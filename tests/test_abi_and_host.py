@@ -166,3 +166,48 @@ def test_public_header_is_valid_c99_and_a_c_host_links_against_the_library(tmp_p
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.startswith('spsp') and 'NULL handle' in out.stdout
+
+
+def test_conv_wres_tile_id_agpr_is_untouched_while_its_atomic_is_in_flight():
+    """conv_wres.hip fetches the id of the tile after next with a returning atomic whose AGPR destination is read a whole
+    tile later (`s_waitcnt vmcnt(0); v_accvgpr_read_b32`).  hipcc considers the asm output written when the statement ends,
+    so nothing but the register allocator's lack of a reason keeps it from copying or reusing that register before the
+    value has arrived.  This reads the generated ISA: walking forward (circularly, the tile loop wraps)
+    from every such atomic, the first instruction that names its AGPR -- other than another such atomic -- must be the
+    waited read."""
+    import shutil
+    import subprocess
+    if shutil.which('hipcc') is None:
+        pytest.skip('no hipcc')
+    csrc = os.path.join(ROOT, 'soccerplayershapepose_amd', 'csrc')
+    subprocess.check_call(['make', '-C', csrc, 'conv_wres.s'], stdout=subprocess.DEVNULL)
+    text = open(os.path.join(csrc, 'conv_wres.s')).read()
+    kernels = [k for k in re.split(r'\n\s*s_endpgm', text) if 'global_atomic_add a' in k]
+    assert kernels, 'no kernel with the in-flight AGPR atomic found (did the scheduler change?)'
+    checked = 0
+    for k in kernels:
+        ins = [ln.split(';')[0].strip() for ln in k.splitlines()]
+        ins = [ln for ln in ins if ln and not ln.startswith(('.', '//')) and not ln.endswith(':')]
+        for i, ln in enumerate(ins):
+            m = re.match(r'global_atomic_add (a\d+),', ln)
+            if not m:
+                continue
+            reg = m.group(1)
+            pat = re.compile(r'(?<![\w\[])' + reg + r'(?![\w:\]])')
+            for step in range(1, len(ins)):
+                j = (i + step) % len(ins)
+                if not pat.search(ins[j]) and not re.search(r'a\[(\d+):(\d+)\]', ins[j]):
+                    continue
+                if re.search(r'a\[(\d+):(\d+)\]', ins[j]) and not pat.search(ins[j]):
+                    lo_hi = [(int(a), int(b)) for a, b in re.findall(r'a\[(\d+):(\d+)\]', ins[j])]
+                    if not any(lo <= int(reg[1:]) <= hi for lo, hi in lo_hi):
+                        continue
+                if re.match(r'global_atomic_add ' + reg + ',', ins[j]):
+                    continue
+                assert re.match(r'v_accvgpr_read_b32 v\d+, ' + reg + '$', ins[j]), f'{reg} touched before its atomic returned: "{ins[j]}"'
+                assert ins[j - 1].startswith('s_waitcnt vmcnt(0)'), f'{reg} read without the wait in front: "{ins[j - 1]}" / "{ins[j]}"'
+                checked += 1
+                break
+            else:
+                raise AssertionError(f'{reg}: the atomic\'s result is never read')
+    assert checked >= len(kernels)

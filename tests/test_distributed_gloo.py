@@ -74,6 +74,65 @@ def test_all_gather_ragged_shards_world2():
         assert ok and shape == (23, 229)
 
 
+def _exchange_worker(rank, world, port, fail_at, q):
+    """RecordExchange set-up with the two library calls stubbed (no GPU here): `fail_at` = 'id' (rank 0 cannot draw the
+    unique id), 'init' (rank 1's communicator init fails) or None."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from soccerplayershapepose_amd.sharding import RecordExchange
+        calls = []
+
+        class Stubbed(RecordExchange):
+            def _draw_unique_id(self):
+                calls.append('id')
+                return (None, 'stub: no RCCL') if fail_at == 'id' else (bytes(range(128)), '')
+
+            def _init_rank(self, id_bytes):
+                calls.append('init')
+                assert id_bytes == bytes(range(128))
+                return (None, 'stub: init failed') if (fail_at == 'init' and self.rank == 1) else (object(), '')
+
+            def _destroy(self, comm):
+                calls.append('destroy')
+
+        ex = Stubbed('cpu', mode='abi')
+        full = torch.from_numpy(_records(10))
+        lo, hi = shard_range(10, world, rank)
+        gathered = ex.all_gather(full[lo:hi].clone(), 10) if ex.mode == 'torch' else None
+        q.put((rank, ex.mode, list(calls), ex.describe(), gathered is None or bool(torch.equal(gathered, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_exchange(fail_at):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, fail_at, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)      # a rank stuck in a one-sided collective would time out here
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_record_exchange_setup_failures_fall_back_on_every_rank_together_world2():
+    """rank 0 failing to draw the RCCL unique id used to be known to rank 0 only -- the other ranks went
+    into the blocking communicator init alone.  Now the id is broadcast with an OK flag: nobody calls init, everybody falls
+    back to torch.distributed, and the fallback exchange works.  Same agreement when the init fails on one rank."""
+    (r0, m0, c0, d0, ok0), (r1, m1, c1, d1, ok1) = _run_exchange('id')
+    assert m0 == m1 == 'torch' and c0 == ['id'] and c1 == [] and ok0 and ok1
+    assert 'spsp_comm_unique_id failed on rank 0' in d0 and 'fell back' in d1
+    (r0, m0, c0, d0, ok0), (r1, m1, c1, d1, ok1) = _run_exchange('init')
+    assert m0 == m1 == 'torch' and c0 == ['id', 'init', 'destroy'] and c1 == ['init'] and ok0 and ok1
+    (r0, m0, c0, d0, _), (r1, m1, c1, d1, _) = _run_exchange(None)
+    assert m0 == m1 == 'abi' and c0 == ['id', 'init'] and c1 == ['init']
+
+
 def test_bench_launcher_starts_the_ranks_itself_world2():
     """`python bench.py --gpus 2` with no launcher around it must itself start 2 ranks (fresh children, before any GPU
     call) and relay ONE JSON line saying n_gpus 2 / dp2.  --cpu-rehearsal swaps the GPU work for the exchange step on

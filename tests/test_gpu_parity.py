@@ -269,9 +269,9 @@ def test_silhouette_render_and_metric_against_restated_neural_renderer(smpl_gpu,
         got = out.silhouettes[b].cpu().numpy()
         assert ref.sum() > 200, 'mesh must be visible'
         bad = int((got != ref).sum())
-        assert bad <= 4, f'mesh {b}: {bad} of 262144 pixels differ from the restated rasteriser'
+        assert bad == 0, f'mesh {b}: {bad} of 262144 pixels differ from the restated rasteriser'     # same fp32 operations, none fused: bit for bit
         m_ref = OSil.silhouette_metric(ref, target)
-        assert abs(out.metric[b].item() - m_ref) <= 2e-5 * m_ref + 60.0       # <= 4 samples of 3.45 each may flip + fp32 sum order
+        assert abs(out.metric[b].item() - m_ref) <= 2e-5 * m_ref              # fp32 block sums against a float64 sum
     # a per-mesh target gives the same numbers as the shared one; rendering without a target gives the same image
     t3 = torch.from_numpy(np.repeat(target[None], B, axis=0)).to(dev)
     out3 = rend(verts, trans, target=t3, return_image=False)
@@ -372,6 +372,34 @@ def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev
     with pytest.raises(ValueError):
         multi_view_optimization(smpl_gpu, np.zeros((1, 5, 23, 3, 3), np.float32), np.zeros((1, 5, 1, 3, 3), np.float32),
                                 np.zeros((1, 5, 10), np.float32), np.ones((1, 5, 3), np.float32), np.zeros((1, 5, 17, 2), np.float32))
+
+
+def test_multi_view_fit_at_the_reference_operating_point_50_epochs_3_rounds(smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """The multi-view fit where the reference runs it: 50 epochs per block, 3 rounds (`S/global_var.py:79`,
+    `PR/player_recon.py:1720`) = 300 epochs, 2 400 forward passes with V = 4 -- one player per mode against the autograd
+    restatement.  Tolerances: run on the host against the same oracle (tests/emul), the kernel's phases end 3e-5 apart after
+    the 300 epochs in the reference's mode (betas only) and 5e-4 with the body pose optimised (193 Adam-normalised parameters,
+    900 steps: the sign sensitivity of DESIGN section 2 accumulates), validation history 2e-4 / 2e-3 relative.  Asserted:
+    1e-4 / 1.5e-3 on parameters, 1e-3 / 5e-3 relative on the history."""
+    from soccerplayershapepose_amd.player_recon import multi_view_optimization
+    from oracle import fit_multiview as OMV
+    from test_fit_multiview_emulation import multiview_case
+    for V, seed, obp in ((4, 19, False), (3, 31, True)):
+        views = multiview_case(smpl_model_np, V, seed=seed)
+        st = lambda k: np.stack([v[k][0] for v in views])[None]
+        out = multi_view_optimization(smpl_gpu, st(0), st(1), st(2), st(3), np.stack([v[4] for v in views])[None],
+                                      interation=50, rounds=3, optimise_body_pose=obp, return_history=True)
+        t = lambda k: torch.from_numpy(np.stack([v[k] for v in views]))
+        ref = OMV.fit_multi_view(oracle_smpl, t(0), t(1), t(2), t(3), [v[4] for v in views], iters=50, rounds=3, stale_pose_cat=not obp)
+        hist = out.val_l2e_history[0].cpu().numpy().reshape(-1)
+        assert hist.shape == (300,)
+        np.testing.assert_allclose(hist, ref['val_history'], rtol=5e-3 if obp else 1e-3, atol=5e-3)
+        devs = dict(cam=np.abs(out.cam_wp[0].cpu().numpy() - ref['cam_wp'][:, 0]).max(),
+                    G=np.abs(out.global_orient[0, :, 0].cpu().numpy() - ref['global_orient'][:, 0, 0]).max(),
+                    betas=np.abs(out.betas[0].cpu().numpy() - ref['betas'][0]).max(),
+                    body=np.abs(out.body_pose[0].cpu().numpy() - ref['body_pose'][0]).max())
+        print(f'multi-view 50 x 3, V = {V}, optimise_body_pose = {obp}: {devs}')
+        assert max(devs.values()) < (1.5e-3 if obp else 1e-4), devs
 
 
 def test_single_view_fit_warm_started_from_its_own_record_continues_the_trajectory(smpl_gpu, smpl_model_np, dev, tmp_path):
@@ -591,6 +619,121 @@ def test_end_to_end_against_oracle_pipeline(regressor_gpu, regressor_gpu_f16, sm
     assert max(per_player) < (3e-3 if precision == 'f16' else 1e-2)
 
 
+def test_north_star_all_32_players_of_the_bench_batch_within_1e_3_m_of_the_fp32_reference_path(regressor_gpu_f16, smpl_gpu, oracle_smpl,
+                                                                                                regressor_sd_np, dev):
+    """BASELINE north star, asserted: the benchmark's own batch (B = 32, fp16 backbone, bench.py's input batch 0) through
+    regressor -> rot6d -> 50-iteration pose+shape fit -> SMPL, ALL 32 players against the all-fp32 CPU oracle run end to end
+    on the same crops and targets: max |vertex difference| < 1e-3 m before AND after the fit (measured 9e-5 / 1.0-1.7e-4)."""
+    from soccerplayershapepose_amd.player_recon import reconstruct_players
+    from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
+    from oracle import regressor as OR, geometry as G, fit as OF
+    B = 32
+    x, _ = S.proxy_crops(B, seed=1234)
+    native = regressor_gpu_f16.pack(torch.from_numpy(x).to(dev))
+    cam0, pose0, shape0 = regressor_gpu_f16(native)
+    R0 = rot6d_to_rotmat(pose0).view(B, 24, 3, 3)
+    pre = smpl_gpu(full_pose=R0, betas=shape0).vertices.cpu()
+    R2, b2, _ = S.pose_params(B, seed=77, body_deg=8, global_deg=10)
+    Rp = torch.matmul(torch.from_numpy(R2).to(dev), R0)
+    jp = smpl_gpu(body_pose=Rp[:, 1:], global_orient=Rp[:, :1], betas=shape0 + torch.from_numpy(b2).to(dev) / 3, return_verts=False).joints
+    tgt = S.fit_targets_from_joints(jp.cpu().numpy(), cam0.cpu().numpy() * np.array([1.1, 1, 1], np.float32), seed=4321)
+    res = reconstruct_players(regressor_gpu_f16, smpl_gpu, native, tgt, fit='pose_shape', iters=50)
+    cam_o, pose_o, shape_o = OR.regressor_forward(regressor_sd_np, x, S.mean_params())
+    R_o = G.rot6d_to_rotmat(pose_o).view(B, 24, 3, 3)
+    with torch.no_grad():
+        pre_o = oracle_smpl(body_pose=R_o[:, 1:], global_orient=R_o[:, :1], betas=shape_o).vertices
+    pre_dev = (pre - pre_o).abs().amax(dim=(1, 2))
+    post_dev = []
+    for i in range(B):
+        r = OF.fit_pose_shape(oracle_smpl, R_o[i:i + 1, 1:], R_o[i:i + 1, :1], shape_o[i:i + 1], tgt[i], cam_o[i:i + 1], iters=50)
+        body, Gm, be, ca, _ = r['last']
+        with torch.no_grad():
+            v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
+        post_dev.append((res.vertices[i].cpu() - v[0]).abs().max().item())
+    print(f'north star, 32 players: pre-fit max {pre_dev.max().item():.3e} m, post-fit median {sorted(post_dev)[16]:.3e} max {max(post_dev):.3e} m')
+    assert pre_dev.max().item() < 1e-3
+    assert max(post_dev) < 1e-3, f'players beyond 1e-3 m after the fit: {[(i, d) for i, d in enumerate(post_dev) if d >= 1e-3]}'
+
+
+def test_batch_256_every_block_of_32_is_bit_identical_and_a_sample_matches_the_oracle(regressor_sd_np, smpl_model_np, oracle_smpl, dev):
+    """BASELINE configs[2]'s workload on one GPU: 256 crops in ONE call (max_batch = 256: 8 IEF blocks, 2 048 layer1 tiles on 256
+    persistent workgroups, 256 fit workgroups, SMPL at B = 256).  (i) every block of 32 crops comes out bit for bit as a
+    B = 32 call computes it -- regressor outputs and final vertices; (ii) backbone stages of a sample of crops against the
+    rounding-emulating oracle; (iii) fit + SMPL of sample players against the oracle from identical regressor outputs."""
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    from soccerplayershapepose_amd.models.smpl_official import SMPL
+    from soccerplayershapepose_amd.player_recon import reconstruct_players
+    from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
+    from oracle import regressor as OR, fit as OF
+    B = 256
+    big = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(regressor_sd_np).to(dev)
+    ref = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=32, precision='f16').load_state_dict(regressor_sd_np).to(dev)
+    smpl_big, smpl_ref = SMPL(smpl_model_np, max_batch=B).to(dev), SMPL(smpl_model_np, max_batch=32).to(dev)
+    with pytest.raises(ValueError):
+        SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=257).load_state_dict(regressor_sd_np).to(dev)
+    natives = []
+    xs = {}
+    for blk in range(8):                        # 32 crops at a time on the host (1.2 GB of fp32 otherwise)
+        x, _ = S.proxy_crops(32, seed=300 + blk)
+        natives.append(big.pack(torch.from_numpy(x).to(dev)))
+        xs[blk] = x
+    native = torch.cat(natives)
+    del natives
+    cam, pose, shape = big(native)
+    R0 = rot6d_to_rotmat(pose).view(B, 24, 3, 3)
+    sample = [0, 37, 128, 255]
+    stages = {si: big.read_stage(si, B)[sample].cpu() for si in (1, 2, 3, 4, 5)}
+    tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(5)) * 200 + 150).to(dev)
+    res = reconstruct_players(big, smpl_big, native, tgt, fit='pose_shape', iters=50)
+    assert torch.isfinite(res.vertices).all()
+    for blk in range(8):
+        lo, hi = 32 * blk, 32 * blk + 32
+        c, p, s_ = ref(native[lo:hi])
+        assert torch.equal(cam[lo:hi], c) and torch.equal(pose[lo:hi], p) and torch.equal(shape[lo:hi], s_), f'block {blk}: regressor outputs'
+        if blk in (0, 5, 7):
+            r32 = reconstruct_players(ref, smpl_ref, native[lo:hi], tgt[lo:hi], fit='pose_shape', iters=50)
+            assert torch.equal(res.vertices[lo:hi], r32.vertices) and torch.equal(res.cam[lo:hi], r32.cam), f'block {blk}: fit / SMPL'
+    # (ii) stages of the sample crops against the fp16-emulating oracle
+    xsamp = np.stack([xs[i // 32][i % 32] for i in sample])
+    _, ost = OR.encoder_forward(regressor_sd_np, xsamp, emulate_bf16='f16', return_stages=True)
+    for si, n in ((1, 'maxpool'), (2, 'layer1'), (3, 'layer2'), (4, 'layer3'), (5, 'layer4')):
+        err, scale = (stages[si] - ost[n]).abs().max().item(), ost[n].abs().max().item()
+        assert err <= 0.02 * 0.125 * scale, f'stage {n} at B = 256: max err {err} vs scale {scale}'
+    # (iii) fit + SMPL kernels at B = 256 against the oracle, from the GPU's own regressor outputs
+    for i in sample:
+        r = OF.fit_pose_shape(oracle_smpl, R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape[i:i + 1].cpu(), tgt[i].cpu().numpy(),
+                              cam[i:i + 1].cpu(), iters=50)
+        body, Gm, be, ca, _ = r['last']
+        with torch.no_grad():
+            v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
+        assert (res.vertices[i].cpu() - v[0]).abs().max().item() < 1e-3, f'player {i} of 256'
+
+
+def test_ief_hand_off_time_out_is_reported_as_an_error_not_as_silent_nans(regressor_sd_np, dev):
+    """a starved grid-wide hand-off of the fused IEF used to leave NaNs and SPSP_OK.  The test hook launches
+    the next forward's IEF one workgroup short (its hand-offs can never complete; short spin bound): the outputs are NaN,
+    `check_status()` / the next forward raise, and the handle works again afterwards."""
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=8, precision='f16').load_state_dict(regressor_sd_np).to(dev)
+    x, _ = S.proxy_crops(4, seed=2)
+    native = reg.pack(torch.from_numpy(x).to(dev))
+    good = reg(native)
+    torch.cuda.synchronize()
+    reg.check_status()
+    r = reg._rt
+    r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_IEF_STALL, 1), 'spsp_regressor_debug')
+    cam, pose, shape = reg(native)
+    torch.cuda.synchronize()
+    assert torch.isnan(cam).all() and torch.isnan(shape).all()
+    with pytest.raises(RuntimeError, match='timed out'):
+        reg(native)                                   # the failure of the earlier forward surfaces on the next call ...
+    again = reg(native)                               # ... once; the handle itself is fine
+    torch.cuda.synchronize()
+    reg.check_status()
+    assert all(torch.equal(a, b) for a, b in zip(good, again))
+
+
+
 def test_predict_3d_mirror(regressor_gpu, smpl_gpu, dev):
     from soccerplayershapepose_amd.predict.predict_3D import predict_3D, create_proxy_representation
     sil = np.zeros((512, 512)); sil[100:420, 180:330] = 1
@@ -775,14 +918,17 @@ def test_gpu_proxy_builder_is_bit_identical_to_the_reference_routine(regressor_g
 
 # ---------------------------------------------------------------- BASELINE configs 4 and 5 as parity cases
 def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu, oracle_smpl, smpl_model_np, dev):
-    """Config 4: one match frame = 22 players in one call (ragged w.r.t. every tile size).  Config 5: a short clip in
-    which frame t's fit starts from frame t-1's result (`single_view_optimization` given the previous record as the
-    warm start) while the targets move smoothly; two of the players are followed through the whole clip
-    by the CPU oracle doing the same chain.  Tolerance: 2e-4 on raw parameters per frame, 1e-3 m on final vertices."""
+    """Config 4: one match frame = 22 players in one call (ragged w.r.t. every tile size).  Config 5: the 30-frame clip in
+    which frame t's fit starts from frame t-1's result (`single_view_optimization` given the previous record as the warm
+    start) while the targets move smoothly (2 deg / frame).  Two of the players are followed through the whole
+    clip by the CPU oracle in two ways: TEACHER-FORCED (every frame the oracle fit starts from the GPU's previous state:
+    2e-4 on raw parameters at each of the 30 frames -- per-frame errors cannot hide behind each other) and FREE-RUNNING (the
+    oracle chains its own results from the same regressor outputs: 2e-4 per frame over the first three frames, and the final
+    vertices after 30 chained fits within the north-star 1e-3 m)."""
     from soccerplayershapepose_amd.player_recon import reconstruct_players, single_view_optimization
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
     from oracle import fit as OF, smpl as OS
-    N, T, follow = 22, 3, (0, 21)
+    N, T, follow = 22, 30, (0, 21)
     x, _ = S.proxy_crops(N, seed=31)
     xt = torch.from_numpy(x).to(dev)
     cam0, pose0, shape0 = regressor_gpu(xt)
@@ -799,24 +945,38 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
     res = reconstruct_players(regressor_gpu, smpl_gpu, xt, targets[0], fit='pose_shape', iters=50)
     assert res.vertices.shape == (N, 6890, 3) and torch.isfinite(res.vertices).all()
     body, orient, betas, cam = res.rotmats[:, 1:], res.rotmats[:, :1], res.betas, res.cam
-    # the oracle follows two players through the same chain, started from the same regressor outputs
-    o = {i: (R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape0[i:i + 1].cpu(), cam0[i:i + 1].cpu()) for i in follow}
+    start = {i: (R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape0[i:i + 1].cpu(), cam0[i:i + 1].cpu()) for i in follow}
+    free = dict(start)          # the oracle's own chain
+    forced = dict(start)        # what the GPU fit of the coming frame starts from
+    worst_forced = worst_free = 0.0
     for t in range(T):
         if t > 0:
             rec = single_view_optimization(smpl_gpu, body, orient, betas, cam, targets[t], interation=50)
             body, orient, betas, cam = rec.body_pose, rec.global_orient, rec.betas, rec.cam_wp
         for i in follow:
-            r = OF.fit_pose_shape(oracle_smpl, o[i][0], o[i][1], o[i][2], targets[t][i], o[i][3], iters=50)
-            ob, og, obe, oc, _ = r['last']
-            o[i] = (ob.detach(), og.detach(), obe.detach(), oc.detach())
-            assert (body[i].cpu() - ob[0]).abs().max().item() < 2e-4, f'frame {t} player {i}: body pose'
-            assert (orient[i].cpu() - og[0]).abs().max().item() < 2e-4
-            assert (betas[i].cpu() - obe[0]).abs().max().item() < 2e-4 and (cam[i].cpu() - oc[0]).abs().max().item() < 2e-4
+            gpu_now = (body[i:i + 1].cpu(), orient[i:i + 1].cpu(), betas[i:i + 1].cpu(), cam[i:i + 1].cpu())
+            ob, og, obe, oc, _ = OF.fit_pose_shape(oracle_smpl, *forced[i][:3], targets[t][i], forced[i][3], iters=50)['last']
+            d = max((gpu_now[0] - ob).abs().max().item(), (gpu_now[1] - og).abs().max().item(), (gpu_now[2] - obe).abs().max().item(),
+                    (gpu_now[3] - oc).abs().max().item())
+            worst_forced = max(worst_forced, d)
+            assert d < 2e-4, f'frame {t} player {i}: {d} from the oracle fit started at the same state'
+            forced[i] = gpu_now
+            fb, fg, fbe, fc, _ = OF.fit_pose_shape(oracle_smpl, *free[i][:3], targets[t][i], free[i][3], iters=50)['last']
+            free[i] = (fb.detach(), fg.detach(), fbe.detach(), fc.detach())
+            d = max((gpu_now[0] - fb).abs().max().item(), (gpu_now[1] - fg).abs().max().item(), (gpu_now[2] - fbe).abs().max().item(),
+                    (gpu_now[3] - fc).abs().max().item())
+            worst_free = max(worst_free, d)
+            if t < 3:
+                assert d < 2e-4, f'frame {t} player {i}: {d} from the free-running oracle chain'
     out = smpl_gpu(body_pose=body, global_orient=orient, betas=betas)
+    vdev = 0.0
     for i in follow:
         with torch.no_grad():
-            v = oracle_smpl(body_pose=o[i][0], global_orient=o[i][1], betas=o[i][2]).vertices[0]
-        assert (out.vertices[i].cpu() - v).abs().max().item() < 1e-3
+            v = oracle_smpl(body_pose=free[i][0], global_orient=free[i][1], betas=free[i][2]).vertices[0]
+        vdev = max(vdev, (out.vertices[i].cpu() - v).abs().max().item())
+    print(f'30-frame clip: worst per-frame parameter deviation teacher-forced {worst_forced:.2e}, free-running {worst_free:.2e}; '
+          f'final vertices vs the free-running oracle chain {vdev:.2e} m')
+    assert vdev < 1e-3
 
 
 # ---------------------------------------------------------------- PoseRelationModule (8f-2)
