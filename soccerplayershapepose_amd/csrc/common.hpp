@@ -101,6 +101,7 @@ enum KernelId {
     kKPatchW8,         // conv3x3_patch_kernel<true, ...>  (3x3 / 1 of layer4: four 8 x 8 images per tile)
     kKConvRing,        // conv_ring_kernel<...> (stride-2 3x3 and 1x1 convs; every conv of a ragged batch)
     kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate,
+    kKConvS2,          // conv3x3s2_kernel (the three 3x3 / 2 convs + their fused 1x1 / 2 downsamples, parity-plane patch)
     kKNumKernels
 };
 struct ProfRec { int id; hipEvent_t start, stop; hipStream_t stream; };

@@ -49,6 +49,13 @@ int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 bool conv_patch_supported(const ConvArgs& a);
 int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, int ring_groups, hipStream_t stream);
 
+int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels);   // XCDs along the channel blocks for the fewest fabric bytes
+
+// conv_s2.hip: the 3x3 stride-2 conv of a residual stage with the stage's 1x1 stride-2 downsample riding on it (w2 / bias2 /
+// out2 / n2), on an LDS-resident patch split into the four parity planes of the input; 128 output pixels x 64 channels per workgroup
+bool conv_s2_supported(const ConvArgs& a);
+int launch_conv_s2(const ConvArgs& a, hipStream_t stream);
+
 // conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
 bool conv_wres_supported(const ConvArgs& a);
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);

@@ -14,14 +14,17 @@
 // pixel index q: f = q & 7 for the 16-pixel-row tiles -- conflict-free for ds_read_b128, whose four lane groups
 // {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... each touch 16 DISTINCT 16-byte bank slots ((a / 16) mod 16) for any
 // 16 consecutive pixels (the first version used (q >> 1) & 7: 2-way conflicts at 3 of 4 tap positions, 8 LDS cycles
-// per fragment read instead of 4; model: tools/lds_bank_check.py).  The 8 x 8-map tiles (two 8-pixel rows per
-// fragment) keep (q >> 1) & 7: no linear swizzle is conflict-free for that shape.
+// per fragment read instead of 4; model: tools/lds_bank_check.py).  The 8 x 8 maps get the same reads by INTERLEAVING two
+// images along the columns of the patch (patch column c' = 2 col + image): an MFMA tile is then 16 consecutive patch pixels
+// = one row of both images, a one-column tap shift is a shift by 2.  (Rounds 1-2 read two 8-pixel rows of ONE image per
+// fragment: no linear swizzle is conflict-free for that shape -- 32 % of the kernel's LDS cycles were bank conflicts.)
 // The image is written by LDS-DMA (lane-linear: 8 pixels x 8 chunks per wave-instruction, swizzle applied on the
 // SOURCE chunk) and read with ds_read_b128; the 36 per-lane fragment offsets (9 taps x 4 tiles) live in registers.
 //
 // Tile geometries (W = feature-map width = height):
 //   W >= 16 : tile = 16 x 16 pixels of one image, patch 18 x 18; wave w owns rows 4w..4w+3, MFMA tile j = one row.
-//   W == 8  : tile = 4 whole 8 x 8 images, patch 4 x (10 x 10); wave w owns image w, MFMA tile j = rows 2j, 2j+1.
+//   W == 8  : tile = NPG whole 8 x 8 images = NPG / 2 interleaved pairs, patch (NPG / 2) x (10 x 20); pixel group w owns
+//             rows 4 (w & 1) .. + 3 of BOTH images of pair w >> 1, MFMA tile j = row 4 (w & 1) + j, lane = 2 col + image.
 //
 // One structure (the per-tap-ring forms of the first round are gone): 2 NPG waves = NPG 64-pixel groups x 2 K-halves; wave
 // pairs (w, w + NPG) split every 64-deep K-step in halves and exchange accumulators through LDS at the end; GROUPED weight
@@ -98,7 +101,7 @@ constexpr int kPixB = 128;                   // bytes per patch pixel (64 ch)
 __host__ __device__ constexpr int acc_channel(int i, int r) { return 32 * (i >> 1) + 8 * (r >> 2) + 4 * (i & 1) + (r & 3); }
 
 template <bool W8>
-__device__ __forceinline__ int patch_swz(int q) { return W8 ? ((q >> 1) & 7) : (q & 7); }
+__device__ __forceinline__ int patch_swz(int q) { return q & 7; }
 
 // NPG = 64-pixel groups per tile: 4 (256-pixel tile, 8 waves) or 2 (128-pixel tile, 4 waves -- twice the workgroups, for
 // the layers whose 256-pixel tiles leave most of the chip idle: layer3 has 128 of them, layer4 64)
@@ -106,7 +109,8 @@ template <bool W8, int NPG>
 struct Geo {
     static constexpr int NW = 2 * NPG;                            // waves per workgroup (pixel groups x 2 K-halves)
     static constexpr int TPIX = 64 * NPG;                         // output pixels per tile
-    static constexpr int PW = W8 ? 10 : 18;                       // patch row pitch in pixels
+    static constexpr int PW = W8 ? 20 : 18;                       // patch row pitch in pixels (8 x 8 maps: 10 columns x 2 interleaved images)
+    static constexpr int DXS = W8 ? 2 : 1;                        // patch-pixel shift of a one-column tap shift
     static constexpr int NPIX = W8 ? 100 * NPG : (4 * NPG + 2) * 18;   // patch pixels
     static constexpr int NDMA = (NPIX + 7) / 8;                   // 8 pixels per wave-instruction
     static constexpr int PATCH = NDMA * 8 * kPixB;                // bytes (padded to whole DMA pieces)
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         q = q < G::NPIX ? q : G::NPIX - 1;                         // tail lanes re-read the last pixel (harmless)
         int off;
         if constexpr (W8) {
-            const int im = q / 100, r = q - im * 100, py = r / 10, px = r - py * 10;
-            off = (img0 + im) * a.in_img + py * a.in_row + px * a.in_pix;
+            const int pair = q / 200, r = q - pair * 200, py = r / 20, cc = r - py * 20;      // cc = 2 px + image of the pair
+            off = (img0 + 2 * pair + (cc & 1)) * a.in_img + py * a.in_row + (cc >> 1) * a.in_pix;
         } else {
             const int py = q / 18, px = q - py * 18;
             off = img0 * a.in_img + (y0 + py) * a.in_row + (x0 + px) * a.in_pix;
@@ -211,11 +215,10 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
     // weight fragment reads: row t*16 + frow, chunk (ks*4 + fq) ^ (frow & 7)
     const uint32_t w_lane = frow * 128 + ((fq ^ (frow & 7)) * 16);
-    // patch pixel index of this lane for MFMA tile j = qb + j * QJ (tap adds r*PW + s)
+    // patch pixel index of this lane for MFMA tile j = qb + j * PW (tap (ky, dx) adds ky * PW + dx * DXS)
     int qb;
-    if constexpr (W8) qb = wave * 100 + (frow >> 3) * 10 + (frow & 7);
+    if constexpr (W8) qb = (wave >> 1) * 200 + (4 * (wave & 1)) * PW + frow;
     else qb = (wave * 4) * 18 + frow;
-    constexpr int QJ = W8 ? 20 : 18;
 
     // LDS byte offsets of this lane's pixel fragments (chunk-independent: registers for the whole kernel).
     //   W >= 16 : MFMA tile j of tap (ky, dx) is patch row j + ky shifted by dx pixels, so the three taps of a kernel COLUMN
@@ -224,25 +227,16 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     //             by a quarter (24 -> 18 per three taps) -- they, not the MFMAs, set the pace of the loop: 8 waves x 8
     //             ds_read_b128 x 8 cycles = the 512 cycles 16 MFMAs per wave take, before the LDS-DMA writes.
     //   W == 8  : a fragment is two 8-pixel rows, a one-row shift is not a fragment: all 36 (tap, j) addresses.
-    constexpr bool ROWS = !W8;
-    uint32_t xoff[ROWS ? 3 : 9][ROWS ? 6 : 4];
-    if constexpr (ROWS) {
+    //   (since round 3 the 8 x 8 maps are interleaved pairs and take the same form with a column shift of 2)
+    constexpr bool ROWS = true;
+    uint32_t xoff[3][6];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int q = qb + r * PW + dx;
-                xoff[dx][r] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
-            }
-    } else {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = qb + j * QJ + (tap / 3) * PW + (tap % 3);
-                xoff[tap][j] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
-            }
-    }
+        for (int r = 0; r < 6; ++r) {
+            const int q = qb + r * PW + dx * G::DXS;
+            xoff[dx][r] = smem_base + kNS * kWStage + q * kPixB + ((((KS == 2 ? kw * 4 : 0) + fq) ^ patch_swz<W8>(q)) * 16);
+        }
 
     // K order inside the kernel: chunk-major, then the kernel's columns (ROWS) or rows (W8), then the other tap index; the
     // weight matrix is stored tap-major/chunk-minor like the implicit-GEMM kernels, so step (ch, tap) reads K-step
@@ -310,17 +304,14 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         P_SB                                                                                              \
     }
     // Step T (0..2) of group R of a chunk with parity P0; s = 3 R + T is its place in the chunk, set = (s + P0) & 1.
-    //   ROWS: group = kernel column R, tap (ky = T, dx = R): pixels xw[GP][T..T+3], GP = (P0 + R) & 1; the step before it
-    //         used xw[GP][T-1 ..] (T > 0) or the previous group's xw[GP ^ 1][2 ..].
-    //   W8  : group = kernel row R, tap 3 R + T: pixels xw[set][0..3] <- xoff[tap][0..3].
+    //   group = kernel column R, tap (ky = T, dx = R): pixels xw[GP][T..T+3], GP = (P0 + R) & 1; the step before it
+    //   used xw[GP][T-1 ..] (T > 0) or the previous group's xw[GP ^ 1][2 ..].
     // ring third of group R of a chunk with parity P0: g % NG with g = 3 ch + R
 #define P_GSLOT(R, P0) ((NG == 3 ? (R) : (((P0) + (R)) & 1)) * 3)
 #define SPSP_STEP(R, T, P0, FIRST)                                                                        \
-    if constexpr (ROWS) {                                                                                 \
+    {                                                                                                     \
         if constexpr ((T) == 0) SPSP_GTAP((3 * (R) + (P0)) & 1, P_GSLOT(R, P0), true, ((P0) + (R)) & 1, 0, R, 0, (((P0) + (R)) & 1) ^ 1, 2, FIRST, 3) \
         else SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, P_GSLOT(R, P0) + (T), false, ((P0) + (R)) & 1, (T) + 3, R, (T) + 3, ((P0) + (R)) & 1, (T) - 1, FIRST, (T) == 2 ? 0 : 3) \
-    } else {                                                                                              \
-        SPSP_GTAP((3 * (R) + (T) + (P0)) & 1, P_GSLOT(R, P0) + (T), true, (3 * (R) + (T) + (P0)) & 1, 0, 3 * (R) + (T), 0, ((3 * (R) + (T) + (P0)) & 1) ^ 1, 0, FIRST, (T) == 2 ? 0 : 3) \
     }
 
     CSTAMP(0);
@@ -398,7 +389,8 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     // loaded straight into registers before the exchange (its latency sits under the two barriers), the result is stored
     // straight from registers: no staging tile, no barrier after the exchange.  tile pixel tp = wave*64 + j*16 + frow.
     auto pix_off = [&](int tp) -> size_t {
-        if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + (tp >> 6)) * a.out_img + (size_t)((tp >> 3) & 7) * a.out_row + (size_t)(tp & 7) * a.out_pix;
+        // 8 x 8 maps: pixel group w = tp >> 6 holds rows 4 (w & 1) + j of the two images of pair w >> 1, lane = 2 col + image
+        if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + 2 * (tp >> 7) + (tp & 1)) * a.out_img + (size_t)(4 * ((tp >> 6) & 1) + ((tp >> 4) & 3)) * a.out_row + (size_t)((tp & 15) >> 1) * a.out_pix;
         else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
     };
     const int cbase = n_blk + 32 * kw + 8 * fq;
@@ -468,13 +460,24 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         }
         if constexpr (W8) {
             if (a.pool_out) {
-                // fused global average pool (resnet.py:157): this wave holds all 64 pixels of image img0 + wave
-                const int b = img0 + wave;
+                // fused global average pool (resnet.py:157).  This wave holds 32 pixels (rows 4 (wave & 1) .. + 3) of each image of
+                // its pair, lane parity = image: sum over the 8 columns by shuffles, hand the halves to each other through LDS
+                // (behind the K-half exchange area), the even wave of the pair adds in a fixed order and stores.
+                float* const px_ = reinterpret_cast<float*>(smem + NW * 8192);          // [wave][image 2][fq 4][8]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = psum[e];
-                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                    if (frow == 0) a.pool_out[(size_t)b * a.N + cbase + e] = v * (1.0f / 64.0f);
+                    v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    psum[e] = v;
+                    if (frow < 2) px_[((wave_id * 2 + frow) * 4 + fq) * 8 + e] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if ((wave & 1) == 0 && frow < 2) {
+                    const int b = img0 + 2 * (wave >> 1) + frow;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        a.pool_out[(size_t)b * a.N + cbase + e] = (psum[e] + px_[(((wave_id ^ 1) * 2 + frow) * 4 + fq) * 8 + e]) * (1.0f / 64.0f);
                 }
             }
         }
@@ -489,7 +492,8 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, NPG>;
     constexpr size_t lds = (size_t)3 * NG * kWStage + (DB ? 2 : 1) * G::PATCH;
     static_assert(lds <= 160 * 1024, "one CU has 160 KB of LDS");
-    static_assert(lds >= (size_t)G::NW * 8192, "K-half exchange");
+    static_assert(lds >= (size_t)G::NW * 8192 + (size_t)G::NW * 256, "K-half exchange + pooled-sum hand-over");
+    static_assert(!W8 || NPG % 2 == 0, "8 x 8 maps are tiled in interleaved pairs of images");
     SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG, NG>>((int)lds)));
     const int grid = (a.M / G::TPIX) * (a.N / 64);
 #ifdef SPSP_CONV_STAMPS

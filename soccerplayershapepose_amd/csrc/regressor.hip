@@ -269,7 +269,8 @@ struct spsp_regressor {
     unsigned int* err_host = nullptr;   // pinned, mapped, coherent host word: device-side failures of this handle's kernels (bit 0: IEF hand-off time-out)
     unsigned int* err_dev = nullptr;    // the same word as the kernels see it
     int ief_capacity = 0;               // IEF workgroups the device can hold at once (occupancy x CUs)
-    int debug_ief_stall = 0;            // test hook (spsp_regressor_debug): the next forward's IEF cannot complete its hand-offs
+    int debug_ief_stall = 0;
+    bool use_s2 = true;                 // stride-2 stages on conv_s2.hip (experiment builds: SPSP_NO_S2 = the ring kernel of round 2)            // test hook (spsp_regressor_debug): the next forward's IEF cannot complete its hand-offs
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
 
@@ -311,6 +312,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
+    if (r->use_s2 && conv_s2_supported(a)) {           // 3x3 / 2 + its 1x1 / 2 downsample in whole 128-pixel tiles: parity-plane patch kernel
+        ProfScope ps(ctx, kKConvS2, st, true);
+        return launch_conv_s2(a, st);
+    }
     const RingTile rt = r->ring[L];
     const int bm = (rt == kRing64x128s3 || rt == kRing64x64s4) ? 64 : 128;
     const int bn = (rt == kRing128x64s3 || rt == kRing128x64s4 || rt == kRing64x64s4) ? 64 : 128;
@@ -451,6 +456,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
             (void)sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
             for (int L = 0; L < 4; ++L) if (d[L] >= 0 && d[L] < (int)kRingNone) r->ring[L] = (RingTile)d[L];
         }
+        if (getenv("SPSP_NO_S2")) r->use_s2 = false;
         if (const char* e = getenv("SPSP_PATCH_DB")) {
             int d[4] = {0, 0, 1, 1};
             (void)sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
