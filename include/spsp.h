@@ -179,6 +179,11 @@ int spsp_regressor_status(spsp_regressor* r);
 /* Test hooks.  SPSP_DEBUG_IEF_STALL (value != 0): the NEXT forward launches its IEF one workgroup short of what its
  * hand-offs wait for, with a short spin bound -- exercises the time-out report without hanging anything. */
 #define SPSP_DEBUG_IEF_STALL 1
+/* Plan switches for A/B measurements inside one process (tools/ab_plan.py); results are parity-checked in every setting:
+ * SPSP_DEBUG_PLAN_S2 (0: the stride-2 stages on the round-2 implicit-GEMM ring kernel, 1: parity-plane patch kernel, default),
+ * SPSP_DEBUG_PLAN_LAYER4_CHANNELS (64 or 32 output channels per workgroup of layer4's 3x3 convolutions; default 32). */
+#define SPSP_DEBUG_PLAN_S2 2
+#define SPSP_DEBUG_PLAN_LAYER4_CHANNELS 3
 int spsp_regressor_debug(spsp_regressor* r, int what, int value);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
  * (1 maxpool, 2..5 layer1..layer4; stage 0 -- conv1+relu -- no longer exists as a map since conv1 and the max-pool are one

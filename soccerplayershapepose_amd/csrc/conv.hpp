@@ -45,11 +45,11 @@ struct ConvArgs {
 enum RingTile { kRing128x128s3 = 0, kRing128x128s2, kRing128x64s3, kRing128x64s4, kRing64x128s3, kRing64x64s4, kRingNone };
 int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 
-// third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 px x 64 ch per workgroup
+// third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 / 128 px x 64 / 32 ch per workgroup
 bool conv_patch_supported(const ConvArgs& a);
-int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, int ring_groups, hipStream_t stream);
+int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, hipStream_t stream);
 
-int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels);   // XCDs along the channel blocks for the fewest fabric bytes
+int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels = 64);   // XCDs along the channel blocks for the fewest fabric bytes
 
 // conv_s2.hip: the 3x3 stride-2 conv of a residual stage with the stage's 1x1 stride-2 downsample riding on it (w2 / bias2 /
 // out2 / n2), on an LDS-resident patch split into the four parity planes of the input; 128 output pixels x 64 channels per workgroup

@@ -47,6 +47,9 @@
 #include "conv.hpp"
 #include "conv_elem.hpp"
 
+// (the step macros index fragment arrays with literal constants inside `if (<literal false>)` branches)
+#pragma clang diagnostic ignored "-Warray-bounds"
+
 namespace {
 using namespace spsp;
 
@@ -69,7 +72,6 @@ __device__ __forceinline__ void dma16(const uint16_t* gsrc, unsigned char* lds_w
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-constexpr int kWStage = 64 * 128;            // [64 n][64 k] bf16
 
 #ifdef SPSP_CONV_STAMPS
 #define CSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
@@ -117,12 +119,16 @@ struct Geo {
     static constexpr int DPW = (NDMA + NW - 1) / NW;              // patch DMA instructions per wave
 };
 
-// One workgroup: TPIX pixels x 64 channels.  grid = (M/TPIX) * (N/64).
-template <bool W8, bool F16, bool DB, int NPG, int NG>
+// One workgroup: TPIX pixels x (16 NCT) channels.  grid = (M/TPIX) * (N / (16 NCT)).
+// NCT = channel tiles (of 16) per wave: 4 (64-channel blocks) or 2 (32-channel blocks -- twice the workgroups, for layer4 whose
+// 128 blocks of 128 pixels x 64 channels fill half the chip and whose 776 KB of staging per workgroup, not its MFMAs, set its time).
+template <bool W8, bool F16, bool DB, int NPG, int NG, int NCT = 4>
 __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs a) {
     using G = Geo<W8, NPG>;
     constexpr int PW = G::PW, kNS = 3 * NG, NW = G::NW, KS = 2;   // NG = ring depth in groups of three slabs (2 or 3)
+    constexpr int NCH = 16 * NCT, kWStage = NCH * 128;            // (shadows the file-level constant)
     static_assert(NG == 2 || NG == 3, "ring depth");
+    static_assert(NCT == 4 || (NCT == 2 && NW == 4), "32-channel blocks: four waves (one slab piece each)");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* const ring = smem;                              // kNS x 8 KB weight stages
     unsigned char* const patch0 = smem + kNS * kWStage;            // the patch
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     const int wave = wave_id & (NPG - 1);                          // which 64 pixels of the tile
     const int kw = wave_id / NPG;                                  // KS == 2: which 32-deep half of every K-step
     const int W = a.Wo;                                            // == Ho, == input W (stride 1)
-    const int mt = a.M / G::TPIX, nb = a.N / 64;
+    const int mt = a.M / G::TPIX, nb = a.N / NCH;
     int m_tile, n_blk;
     {
         // blocks b, b+8, b+16 ... share an XCD (round-robin dispatch; a speed assumption only): XCD x = b & 7 owns the
@@ -143,10 +149,10 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         if (XN > 0 && mt % XM == 0 && nb % XN == 0) {
             const int x = bid & 7, li = bid >> 3, nbl = nb / XN;
             m_tile = (x / XN) * (mt / XM) + li / nbl;
-            n_blk = ((x % XN) * nbl + li % nbl) * 64;
+            n_blk = ((x % XN) * nbl + li % nbl) * NCH;
         } else {
             m_tile = bid / nb;
-            n_blk = (bid % nb) * 64;
+            n_blk = (bid % nb) * NCH;
         }
     }
 
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         }
     };
     // ---- weight ring sources: stage = [64 n][64 k] of K-step g (tap-major, chunk-minor: g = tap*nchunks + ch) ----
-    constexpr int LPS = 8 / NW;                                    // weight pieces per wave per stage (8 per stage)
+    constexpr int LPS = (2 * NCT) / NW;                            // weight pieces per wave per stage (2 NCT pieces of 8 rows per stage)
     const uint16_t* w_src[LPS];
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
@@ -205,9 +211,9 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         for (int i = 0; i < LPS; ++i) dma16(w_src[i] + (size_t)g * 64, ring + buf * kWStage + (wave_id * LPS + i) * 1024);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NCT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NCT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     // third group g-1 was read from, then the three taps run back to back -- 48 MFMAs per wave between barriers.
     // Pixel fragments: xw[group parity][row 0..5] (ROWS) -- tap T of a group multiplies rows T..T+3 -- or xw[set][j] (W8).
     // (macros, not lambdas: the fragment arrays must be indexed by literal constants to stay in registers)
-    bf16x8 wfr[2][4], xw[2][ROWS ? 6 : 4];
+    bf16x8 wfr[2][NCT], xw[2][6];
     const uint32_t w_lane_k = smem_base + (w_lane ^ (kw * 64));
 #define P_SB __builtin_amdgcn_sched_barrier(0);
 #ifdef SPSP_PATCH_NOREADS      // diagnosis only: the loop without its fragment reads (garbage results)
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     {                                                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
         P_M2(S1, XP, XT, 0, 0, true) P_M2(S1, XP, XT, 0, 2, true) P_M2(S1, XP, XT, 1, 0, true) P_M2(S1, XP, XT, 1, 2, true) \
-        P_M2(S1, XP, XT, 2, 0, true) P_M2(S1, XP, XT, 2, 2, true) P_M2(S1, XP, XT, 3, 0, true) P_M2(S1, XP, XT, 3, 2, true) \
+        if constexpr (NCT == 4) { P_M2(S1, XP, XT, 2, 0, true) P_M2(S1, XP, XT, 2, 2, true) P_M2(S1, XP, XT, 3, 0, true) P_M2(S1, XP, XT, 3, 2, true) } \
     }
     // One step: its reads (weights -> set SET from ring slab SLOT; pixels: X4 = four fragments, else one) inside the MFMAs of
     // the previous step (weights in set SET^1, pixels xw[MP][MT + j]; none if FIRST).
@@ -285,7 +291,20 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     // The last step of a group ends with ENDW = 0: after the next barrier other waves overwrite the slab it read.
 #define P_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 #define SPSP_GTAP(SET, SLOT, X4, XP, XR, A0, A1, MP, MT, FIRST, ENDW)                                     \
-    {                                                                                                     \
+    if constexpr (NCT == 2) {                                                                             \
+        /* 32-channel blocks: 8 MFMAs per step, reads X.., W0, W1; a step ends when W0 has landed (ENDW = 3 -> 1 here) and */ \
+        /* waits for the previous W1 before channel tile 1, by which time all of its own reads are in flight            */ \
+        P_RX(XP, XR, A0, A1)                                                                              \
+        if (X4) { P_RX(XP, (XR) + 1, A0, (A1) + 1) } else { P_RW(SET, 0, SLOT) }                          \
+        P_M2((SET) ^ 1, MP, MT, 0, 0, !(FIRST))                                                           \
+        if (X4) { P_RX(XP, (XR) + 2, A0, (A1) + 2) P_RX(XP, (XR) + 3, A0, (A1) + 3) } else { P_RW(SET, 1, SLOT) } \
+        P_M2((SET) ^ 1, MP, MT, 0, 2, !(FIRST))                                                           \
+        if (X4) { P_RW(SET, 0, SLOT) P_RW(SET, 1, SLOT) }                                                 \
+        if (X4) { P_WAIT(6) } else { P_WAIT(3) }              /* previous W1 (behind it: 6 or 3 new) */   \
+        P_M2((SET) ^ 1, MP, MT, 1, 0, !(FIRST)) P_M2((SET) ^ 1, MP, MT, 1, 2, !(FIRST))                   \
+        if ((ENDW) == 0) { P_WAIT(0) } else { P_WAIT(1) }                                                 \
+        P_SB                                                                                              \
+    } else {                                                                                              \
         P_RX(XP, XR, A0, A1)                                                                              \
         if (X4) { P_RX(XP, (XR) + 1, A0, (A1) + 1) } else { P_RW(SET, 0, SLOT) }                          \
         P_M2((SET) ^ 1, MP, MT, 0, 0, !(FIRST))                                                           \
@@ -393,30 +412,42 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         if constexpr (W8) return (size_t)a.out_off + (size_t)(img0 + 2 * (tp >> 7) + (tp & 1)) * a.out_img + (size_t)(4 * ((tp >> 6) & 1) + ((tp >> 4) & 3)) * a.out_row + (size_t)((tp & 15) >> 1) * a.out_pix;
         else return (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + (tp >> 4)) * a.out_row + (size_t)(x0 + (tp & 15)) * a.out_pix;
     };
-    const int cbase = n_blk + 32 * kw + 8 * fq;
-    size_t poff[4];
-    uint4 resv[4];
+    // What a wave owns after the K-half exchange, with static register indices:
+    //   NCT = 4: channel tiles I0 = 2 kw, I0 + 1 of all four pixel tiles  (give: the other two channel tiles)
+    //   NCT = 2: both channel tiles of pixel tiles J0 = 2 kw, J0 + 1      (give: the other two pixel tiles)
+    // either way a lane holds 8 consecutive channels, cbase .. cbase + 7, of each of its pixels.
+    constexpr int NJ = NCT == 4 ? 4 : 2;                            // pixel tiles kept
+    const int cbase = n_blk + (NCT == 4 ? 32 * kw : 0) + 8 * fq;
+    const int jbase = NCT == 4 ? 0 : 2 * kw;
+    size_t poff[NJ];
+    uint4 resv[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        poff[j] = pix_off(wave * 64 + j * 16 + frow) + cbase;
-        resv[j] = make_uint4(0, 0, 0, 0);
-        if (a.res) resv[j] = *reinterpret_cast<const uint4*>(a.res + poff[j]);
+    for (int jj = 0; jj < NJ; ++jj) {
+        poff[jj] = pix_off(wave * 64 + (jbase + jj) * 16 + frow) + cbase;
+        resv[jj] = make_uint4(0, 0, 0, 0);
+        if (a.res) resv[jj] = *reinterpret_cast<const uint4*>(a.res + poff[jj]);
     }
     const float4 bias0 = *reinterpret_cast<const float4*>(a.bias + cbase), bias1 = *reinterpret_cast<const float4*>(a.bias + cbase + 4);
     {
-        // Combine the two K-halves: wave (kw, w) keeps channel tiles i = 2kw, 2kw+1 and hands the other two to its
-        // partner through LDS (ring + patch are dead by now; NW waves x 8 KB).  Static register indices only.
+        // Combine the two K-halves through LDS (ring + patch are dead by now; NW waves x 8 KB).  Static register indices only.
         // (raw barriers: __syncthreads() would also wait for the residual loads just issued)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float* xch = reinterpret_cast<float*>(smem);
+        auto slot = [&](int w, int n) { return xch + ((size_t)(w * 8 + n) * 64 + lane) * 4; };
         auto put = [&](auto GIVE) {
             constexpr int g = decltype(GIVE)::value;
+            if constexpr (NCT == 4) {
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+                for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(xch + ((size_t)(wave_id * 8 + ii * 4 + j) * 64 + lane) * 4) = acc[g + ii][j];
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(slot(wave_id, ii * 4 + j)) = acc[g + ii][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) *reinterpret_cast<f32x4*>(slot(wave_id, i * 2 + jj)) = acc[i][g + jj];
+            }
         };
         if (kw == 0) put(std::integral_constant<int, 2>{}); else put(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -424,27 +455,34 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         const int partner = wave_id ^ NPG;
         auto get = [&](auto KEEP) {
             constexpr int k = decltype(KEEP)::value;
+            if constexpr (NCT == 4) {
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+                for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[k + ii][j] += *reinterpret_cast<const f32x4*>(xch + ((size_t)(partner * 8 + ii * 4 + j) * 64 + lane) * 4);
+                    for (int j = 0; j < 4; ++j) acc[k + ii][j] += *reinterpret_cast<const f32x4*>(slot(partner, ii * 4 + j));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acc[i][k + jj] += *reinterpret_cast<const f32x4*>(slot(partner, i * 2 + jj));
+            }
         };
         if (kw == 0) get(std::integral_constant<int, 0>{}); else get(std::integral_constant<int, 2>{});
     }
     CSTAMP(5);
-    auto epilogue = [&](auto I0c) {
-        constexpr int I0 = decltype(I0c)::value;
+    auto epilogue = [&](auto K0c) {
+        constexpr int K0 = decltype(K0c)::value;          // NCT = 4: first channel tile kept; NCT = 2: first pixel tile kept
+        constexpr int I0 = NCT == 4 ? K0 : 0, J0 = NCT == 4 ? 0 : K0;
         float psum[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) psum[e] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 lo4 = acc[I0][j], hi4 = acc[I0 + 1][j];
+        for (int jj = 0; jj < NJ; ++jj) {
+            const f32x4 lo4 = acc[I0][J0 + jj], hi4 = acc[I0 + 1][J0 + jj];
             float v[8] = {lo4[0] + bias0.x, lo4[1] + bias0.y, lo4[2] + bias0.z, lo4[3] + bias0.w,
                           hi4[0] + bias1.x, hi4[1] + bias1.y, hi4[2] + bias1.z, hi4[3] + bias1.w};
             if (a.res) {
-                const uint4 r = resv[j];
+                const uint4 r = resv[jj];
                 v[0] += Elem<F16>::lo(r.x); v[1] += Elem<F16>::hi(r.x); v[2] += Elem<F16>::lo(r.y); v[3] += Elem<F16>::hi(r.y);
                 v[4] += Elem<F16>::lo(r.z); v[5] += Elem<F16>::hi(r.z); v[6] += Elem<F16>::lo(r.w); v[7] += Elem<F16>::hi(r.w);
             }
@@ -455,14 +493,15 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 8; ++e) psum[e] += v[e];
             if (a.out)
-                *reinterpret_cast<uint4*>(a.out + poff[j]) =
+                *reinterpret_cast<uint4*>(a.out + poff[jj]) =
                     make_uint4(Elem<F16>::pack2(v[0], v[1]), Elem<F16>::pack2(v[2], v[3]), Elem<F16>::pack2(v[4], v[5]), Elem<F16>::pack2(v[6], v[7]));
         }
         if constexpr (W8) {
             if (a.pool_out) {
-                // fused global average pool (resnet.py:157).  This wave holds 32 pixels (rows 4 (wave & 1) .. + 3) of each image of
-                // its pair, lane parity = image: sum over the 8 columns by shuffles, hand the halves to each other through LDS
-                // (behind the K-half exchange area), the even wave of the pair adds in a fixed order and stores.
+                // fused global average pool (resnet.py:157).  Lane parity = image of the pair.  A wave holds, of each image, the
+                // pixels of its NJ rows: sum over the 8 columns by shuffles, then the waves that share the image pair and the
+                // channels hand their sums over through LDS (behind the K-half exchange area) and ONE of them adds in a fixed order:
+                //   NCT = 4: waves w, w ^ 1 (rows 4 (w & 1) .. + 3 each);  NCT = 2 (NPG = 2): all four waves (2 rows each).
                 float* const px_ = reinterpret_cast<float*>(smem + NW * 8192);          // [wave][image 2][fq 4][8]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -473,11 +512,23 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if ((wave & 1) == 0 && frow < 2) {
-                    const int b = img0 + 2 * (wave >> 1) + frow;
+                if constexpr (NCT == 4) {
+                    if ((wave & 1) == 0 && frow < 2) {
+                        const int b = img0 + 2 * (wave >> 1) + frow;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        a.pool_out[(size_t)b * a.N + cbase + e] = (psum[e] + px_[(((wave_id ^ 1) * 2 + frow) * 4 + fq) * 8 + e]) * (1.0f / 64.0f);
+                        for (int e = 0; e < 8; ++e)
+                            a.pool_out[(size_t)b * a.N + cbase + e] = (psum[e] + px_[(((wave_id ^ 1) * 2 + frow) * 4 + fq) * 8 + e]) * (1.0f / 64.0f);
+                    }
+                } else {
+                    if (wave_id == 0 && frow < 2) {
+                        const int b = img0 + frow;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float s01 = px_[((0 * 2 + frow) * 4 + fq) * 8 + e] + px_[((1 * 2 + frow) * 4 + fq) * 8 + e];
+                            const float s23 = px_[((2 * 2 + frow) * 4 + fq) * 8 + e] + px_[((3 * 2 + frow) * 4 + fq) * 8 + e];
+                            a.pool_out[(size_t)b * a.N + cbase + e] = (s01 + s23) * (1.0f / 64.0f);
+                        }
+                    }
                 }
             }
         }
@@ -487,15 +538,16 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     CS_WG(1)
 }
 
-template <bool W8, bool F16, bool DB, int NPG, int NG>
+template <bool W8, bool F16, bool DB, int NPG, int NG, int NCT = 4>
 int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, NPG>;
-    constexpr size_t lds = (size_t)3 * NG * kWStage + (DB ? 2 : 1) * G::PATCH;
+    constexpr size_t lds_need = (size_t)3 * NG * (NCT * 16 * 128) + (DB ? 2 : 1) * G::PATCH;
+    constexpr size_t lds_xch = (size_t)G::NW * 8192 + (size_t)G::NW * 256;     // K-half exchange + pooled-sum hand-over reuse the space
+    constexpr size_t lds = lds_need > lds_xch ? lds_need : lds_xch;
     static_assert(lds <= 160 * 1024, "one CU has 160 KB of LDS");
-    static_assert(lds >= (size_t)G::NW * 8192 + (size_t)G::NW * 256, "K-half exchange + pooled-sum hand-over");
     static_assert(!W8 || NPG % 2 == 0, "8 x 8 maps are tiled in interleaved pairs of images");
-    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG, NG>>((int)lds)));
-    const int grid = (a.M / G::TPIX) * (a.N / 64);
+    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT>>((int)lds)));
+    const int grid = (a.M / G::TPIX) * (a.N / (16 * NCT));
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
         ConvArgs b = a;
@@ -505,7 +557,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         (void)hipMemset(b.dbg, 0, nd * sizeof(unsigned long long));
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG, NG>), dim3(grid), dim3(64 * G::NW), (unsigned)lds, st, e0, e1, 0, b);
+        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT>), dim3(grid), dim3(64 * G::NW), (unsigned)lds, st, e0, e1, 0, b);
         (void)hipDeviceSynchronize();
         float kms = 0.f;
         (void)hipEventElapsedTime(&kms, e0, e1);
@@ -531,14 +583,14 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG, NG>, dim3(grid), dim3(64 * G::NW), lds, st, a);
+    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT>, dim3(grid), dim3(64 * G::NW), lds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
 
-template <bool W8, bool DB, int NPG, int NG>
+template <bool W8, bool DB, int NPG, int NG, int NCT = 4>
 int launch(const ConvArgs& a, hipStream_t st) {
-    return a.f16 ? launch_t<W8, true, DB, NPG, NG>(a, st) : launch_t<W8, false, DB, NPG, NG>(a, st);
+    return a.f16 ? launch_t<W8, true, DB, NPG, NG, NCT>(a, st) : launch_t<W8, false, DB, NPG, NG, NCT>(a, st);
 }
 
 }  // namespace
@@ -553,8 +605,8 @@ bool conv_patch_supported(const ConvArgs& a) {
 // How the 8 XCDs are laid over the (pixel tiles) x (channel blocks) grid: XN of them along the channel blocks.  An XCD
 // pulls its share of the weights (1 / XN) and of the input (XN / 8) through the fabric into its own L2; the split with
 // the fewest bytes wins (layer2: 8 x 1, layer4: 2 x 4).
-int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels) {
-    const int mt = a.M / tile_pixels, nb = a.N / 64;
+int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels) {
+    const int mt = a.M / tile_pixels, nb = a.N / block_channels;
     const double wbytes = (double)a.N * a.nsteps * 64 * 2, xbytes = (double)a.M * a.chunks * 64 * 2;
     int best = 0;
     double best_b = 0;
@@ -567,14 +619,17 @@ int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels) {
     return best;      // 0: no split fits (the kernel falls back to channel-block-fastest over the whole grid)
 }
 
-int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, int ring_groups, hipStream_t stream) {
+int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, hipStream_t stream) {
     SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
     SPSP_REQUIRE(!a0.pool_out || a0.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
     SPSP_REQUIRE(tile_pixels == 256 || tile_pixels == 128, "conv_patch: tile of %d pixels", tile_pixels);
     SPSP_REQUIRE(ring_groups == 2 || ring_groups == 3, "conv_patch: weight ring of %d groups", ring_groups);
+    SPSP_REQUIRE(block_channels == 64 || (block_channels == 32 && a0.Wo == 8 && tile_pixels == 128 && ring_groups == 3 && a0.N % 32 == 0),
+                 "conv_patch: %d-channel blocks (64; 32 for 8 x 8 maps in 128-pixel tiles with a three-group ring)", block_channels);
     ConvArgs a = a0;
-    a.xcd_n = conv_patch_xcd_n(a, tile_pixels);
+    a.xcd_n = conv_patch_xcd_n(a, tile_pixels, block_channels);
     const bool db = two_patch_buffers, w8 = a.Wo == 8;
+    if (block_channels == 32) return db ? launch<true, true, 2, 3, 2>(a, stream) : launch<true, false, 2, 3, 2>(a, stream);
     // (8 x 8 maps, 256-pixel tiles: two 50 KB patches do not fit beside a three-group ring -> one patch buffer)
 #define SPSP_PICK(W8, DB, NPG, NG) return launch<W8, DB, NPG, NG>(a, stream)
     if (tile_pixels == 256) {

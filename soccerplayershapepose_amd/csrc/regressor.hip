@@ -266,6 +266,7 @@ struct spsp_regressor {
     bool patch_db[4];      // per residual stage: two patch buffers in the patch kernel
     int patch_tile[4];     // per residual stage: output pixels per patch-kernel tile (256: 8 waves, 128: 4 waves)
     int patch_ring[4];     // per residual stage: depth of the patch kernel's weight ring, in groups of three slabs (2 or 3)
+    int patch_nch[4];      // per residual stage: output channels per patch-kernel workgroup (64; 32 = twice the workgroups, layer4)
     unsigned int* err_host = nullptr;   // pinned, mapped, coherent host word: device-side failures of this handle's kernels (bit 0: IEF hand-off time-out)
     unsigned int* err_dev = nullptr;    // the same word as the kernels see it
     int ief_capacity = 0;               // IEF workgroups the device can hold at once (occupancy x CUs)
@@ -308,7 +309,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
         ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
-        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], st);
+        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], r->patch_nch[L], st);
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
@@ -447,7 +448,9 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // 128-pixel tiles where 256-pixel ones cover half (layer3: 128) or a quarter (layer4: 64) of the 256 CUs
         const int def_tile[4] = {256, 256, 128, 128};
         const int def_ring[4] = {3, 3, 3, 3};
-        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; }
+        // layer4 in 32-channel blocks: 256 workgroups instead of 128, 488 KB instead of 776 KB staged per workgroup
+        const int def_nch[4] = {64, 64, 64, 32};
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; }
 #if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
         if (const char* e = getenv("SPSP_PATCH_RING")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_ring[0], &r->patch_ring[1], &r->patch_ring[2], &r->patch_ring[3]);
@@ -588,9 +591,17 @@ int spsp_regressor_status(spsp_regressor* r) {
 
 int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
     SPSP_REQUIRE(r, "spsp_regressor_debug: NULL handle");
-    SPSP_REQUIRE(what == SPSP_DEBUG_IEF_STALL, "spsp_regressor_debug: unknown hook %d", what);
-    r->debug_ief_stall = value != 0;
-    return SPSP_OK;
+    switch (what) {
+        case SPSP_DEBUG_IEF_STALL: r->debug_ief_stall = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_LAYER4_CHANNELS:
+            SPSP_REQUIRE(value == 32 || value == 64, "spsp_regressor_debug: layer4 blocks of %d channels", value);
+            r->patch_nch[3] = value;
+            return SPSP_OK;
+        default: break;
+    }
+    spsp::set_error("spsp_regressor_debug: unknown hook %d", what);
+    return SPSP_EINVAL;
 }
 
 int spsp_regressor_read_stage(spsp_ctx* ctx, spsp_regressor* r, int stage, int B, float* out_nchw, void* stream) {
