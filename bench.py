@@ -479,6 +479,7 @@ def main():
     # 3,3,3,...; the frame is done when every rank holds every record)
     flo, fhi = shard_range(FRAME_PLAYERS, world, rank)
     fn = fhi - flo
+    reg.set_plan('latency')        # one batch in flight: layer4 on the whole chip (include/spsp.h, SPSP_PLAN_LATENCY)
     lat = []
     for i in range(25):
         barrier()
@@ -491,6 +492,7 @@ def main():
             exchange.all_gather(rec, FRAME_PLAYERS)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t0)
+    reg.set_plan('throughput')
     lat_t = torch.tensor(sorted(lat[5:])[len(lat[5:]) // 2], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(lat_t, op=dist.ReduceOp.MAX)
@@ -559,7 +561,7 @@ def main():
                          'end_to_end_backbone_tflops': FLOP_BACKBONE * world * B * args.steps / elapsed / 1e12,
                          'end_to_end_backbone_frac': FLOP_BACKBONE * B * args.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS},
             'latency': {'workload': f'one {FRAME_PLAYERS}-player match frame (BASELINE configs[3]) through the whole path, nothing else in '
-                                    f'flight, {world} GPU(s)' + (', players sharded 3,3,... + all-gather' if world > 1 else ''),
+                                    f'flight (regressor plan "latency"), {world} GPU(s)' + (', players sharded 3,3,... + all-gather' if world > 1 else ''),
                         'ms': frame_latency_ms},
             'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},

@@ -172,6 +172,13 @@ int spsp_crop_players(spsp_ctx* ctx, const uint8_t* frame, int H, int W, const i
 /* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
                            float* cam, float* pose6d, float* betas, float* feats, void* stream);
+/* Launch plan of the handle's forwards (same results to fp32 summation order; takes effect at the next forward, not inside a
+ * captured graph).  SPSP_PLAN_THROUGHPUT (default): for several batches in flight on different streams -- the kernels with the
+ * least CU time per batch.  SPSP_PLAN_LATENCY: for ONE batch in flight -- layer4's convolutions on twice the workgroups (the whole
+ * chip instead of half of it): shorter launches, more staging traffic. */
+#define SPSP_PLAN_THROUGHPUT 0
+#define SPSP_PLAN_LATENCY    1
+int spsp_regressor_set_plan(spsp_regressor* r, int plan);
 /* SPSP_OK, or SPSP_EHIP when a kernel of an earlier forward on this handle reported a device-side failure (the fused
  * IEF's bounded hand-off wait).  Reads a host-visible status word: no synchronisation, callable at any time -- e.g. after a
  * HIP-graph replay, which makes no library call that could report it.  Reading clears the status. */
@@ -181,9 +188,11 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_IEF_STALL 1
 /* Plan switches for A/B measurements inside one process (tools/ab_plan.py); results are parity-checked in every setting:
  * SPSP_DEBUG_PLAN_S2 (0: the stride-2 stages on the round-2 implicit-GEMM ring kernel, 1: parity-plane patch kernel, default),
- * SPSP_DEBUG_PLAN_LAYER4_CHANNELS (64 or 32 output channels per workgroup of layer4's 3x3 convolutions; default 32). */
+ * SPSP_DEBUG_PLAN_LAYER4_CHANNELS (64 or 32 output channels per workgroup of layer4's 3x3 convolutions; default: the handle's plan),
+ * SPSP_DEBUG_PLAN_PATCH: value = layer (1..3 = layer2..4) * 10000 + tile pixels (128 | 256) * 10 + ring groups (2 | 3) * 2 + two patch buffers (0 | 1). */
 #define SPSP_DEBUG_PLAN_S2 2
 #define SPSP_DEBUG_PLAN_LAYER4_CHANNELS 3
+#define SPSP_DEBUG_PLAN_PATCH 4
 int spsp_regressor_debug(spsp_regressor* r, int what, int value);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
  * (1 maxpool, 2..5 layer1..layer4; stage 0 -- conv1+relu -- no longer exists as a map since conv1 and the max-pool are one
@@ -269,7 +278,7 @@ int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg,
  *      (neural_renderer, camera_mode='projection', K from FOCAL_LENGTH, R = I, image 512, anti-aliasing on; PR/player_recon.py:
  *      1075-1080, 1226-1229), TrainingLossesAndMetricsTracker's silhouette_iou (PR/metrics/train_loss_and_metrics_tracker.py:
  *      224-229) and determine_save_model_weights_this_epoch over both tracked metrics (:291-298, PR/player_recon.py:1259-1271).
- *      Forward only: neural_renderer's approximate backward pass (silhouette LOSS of single_view_optimization_test) is not built. */
+ *      The differentiable half (the silhouette LOSS of single_view_optimization_test) follows below: spsp_silhouette_loss_grad. */
 typedef struct spsp_rasterizer spsp_rasterizer;
 /* faces: host [F,3] int32 vertex ids (smpl.faces, 13776 rows); img_wh: 512; workspace for max_batch meshes per call. */
 int  spsp_rasterizer_load(spsp_ctx* ctx, const int32_t* faces, int F, int max_batch, int img_wh, spsp_rasterizer** out);
@@ -285,14 +294,45 @@ int  spsp_render_silhouettes(spsp_ctx* ctx, spsp_rasterizer* h, const float* ver
 int  spsp_fit_select(spsp_ctx* ctx, const float* l2e_hist, const float* sil_hist, int iters, int B, const float* param_hist, float* R,
                      float* betas, float* cam, int32_t* best_iter, void* stream);
 
+/* ---- the differentiable half of the silhouette term: the loss of single_view_optimization_test
+ *      (PR/player_recon.py:1429-1557; PR/losses/multi_task_loss.py:132-144) and neural_renderer's approximate backward pass,
+ *      restated (un-vendored dependency: parity unpinned; csrc/silhouette_grad.hip, oracle/silhouette_grad.py).
+ *      verts [B,6890,3], translation [B,3], target uint8 0/1 ([B,wh,wh], or one [wh,wh] when target_shared), weight [B] =
+ *      exp(-silhouette_log_var) (required with grad_verts).  Out (each optional): sil_sum [B] = sum_px [p ln(t + 1e-6) +
+ *      (1 - p) ln(1 - t + 1e-6)]; grad_verts [B,6890,3] and grad_translation [B,3] of L = -sil_sum * weight; image [B,wh,wh]
+ *      (equal to spsp_render_silhouettes': the ownership raster and the coverage raster agree). */
+int  spsp_silhouette_loss_grad(spsp_ctx* ctx, spsp_rasterizer* h, const float* verts, const float* translation, float focal, int B,
+                               const uint8_t* target, int target_shared, const float* weight, float* sil_sum, float* grad_verts,
+                               float* grad_translation, float* image, void* stream);
+/* Reverse mode of spsp_smpl_forward's vertices: grad_verts [B,6890,3] -> grad_R [B,24,9], grad_betas [B,10] at (R, betas). */
+int  spsp_smpl_vertices_vjp(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B, const float* grad_verts,
+                            float* grad_R, float* grad_betas, void* stream);
+/* The fit with the silhouette IN the loss (single_view_optimization_test): parameters {global_orient, body_pose idx {0-5, 8-20},
+ * cam, betas, joints2D_log_var, silhouette_log_var}, torch.optim.Adam, `iters` epochs, the LAST iterate left in place.
+ * log_vars [B,2] in/out (the caller initialises them to -ln(weight + 1e-6), multi_task_loss.py:37-46); histories [B,iters] optional:
+ * loss, joints2D_l2es, the silhouette metric (-sil_sum); param_hist [B,iters,231] = [cam | R | betas | log_vars] each epoch
+ * evaluated.  Every epoch is a chain of launches on `stream`; no host synchronisation. */
+typedef struct {
+    int      iters;                              /* 50 (PR/player_recon.py:1457) */
+    double   lr, beta1, beta2, eps;              /* 1e-3 (S/global_var.py:71), torch.optim.Adam defaults */
+    double   joints2d_weight, silhouette_weight; /* 1.0, 1e6 (PR/player_recon.py:851) */
+    uint32_t param_mask;                         /* SPSP_FIT_MASK_POSE_SHAPE */
+    float    img_wh, loss_wh, focal;             /* 512, 256, 5000 */
+} spsp_fit_silhouette_config;
+void spsp_fit_silhouette_config_default(spsp_fit_silhouette_config* c);
+int  spsp_fit_silhouette(spsp_ctx* ctx, spsp_smpl* s, spsp_rasterizer* rast, const spsp_fit_silhouette_config* cfg, float* R, float* betas,
+                         float* cam, float* log_vars, const float* joints2d, const uint8_t* target, int target_shared, int B,
+                         float* loss_hist, float* l2e_hist, float* sil_hist, float* param_hist, void* stream);
+
 /* ---- multi-view joint fit: replaces the optimisation body of multi_view_optimization (PR/player_recon.py:1691-1979):
  *      V <= 4 views of one player share body pose and betas, each view has its camera and global orientation.
  *      `rounds` x { block 1: Adam over the stacked per-view cameras + orientations; block 2: Adam over the shared
  *      parameters }, `iters` epochs per block, an epoch = one train step per view + a validation pass; the iterate with
  *      the lowest mean joints2D_l2es is kept (per block and as the global record that is returned).  optimise_body_pose
  *      = 0 reproduces the reference exactly (its block 2 reaches betas only: the posed tensor is concatenated before
- *      requires_grad is set, :1724-1731); 1 also optimises body_pose idx {0-5, 8-20} as the loop intends.  Views are
- *      visited in order 0..V-1 (the reference shuffles); the silhouette gate of the record is row 8f-4. */
+ *      requires_grad is set, :1724-1731); 1 also optimises body_pose idx {0-5, 8-20} as the loop intends.  This entry visits the
+ *      views in order 0..V-1 and keeps the record by joints2D_l2es alone; spsp_fit_multiview_ordered takes the reference's
+ *      shuffled orders, spsp_fit_multiview_block serves its two-metric record rule. */
 typedef struct {
     int    iters;               /* 50 epochs per block (S/global_var.py:79) */
     int    rounds;              /* 3 (PR/player_recon.py:1720) */
@@ -308,6 +348,23 @@ void spsp_fit_multiview_config_default(spsp_fit_multiview_config* c);
  * val_hist: optional [B, rounds*2*iters] mean joints2D_l2es of every epoch's validation pass. */
 int spsp_fit_multiview(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose,
                        float* betas, float* cam, float* global_orient, const float* joints2d, float* val_hist, void* stream);
+
+/* The same with the views visited in a given order: view_order [rounds * 2 * iters][V] int32 (device), row = the train pass of
+ * (round, block, epoch) -- the reference shuffles the views before every pass (`random.shuffle`, PR/player_recon.py:1748, 1876);
+ * NULL = 0 .. V-1. */
+int spsp_fit_multiview_ordered(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose,
+                               float* betas, float* cam, float* global_orient, const float* joints2d, const int32_t* view_order,
+                               float* val_hist, void* stream);
+/* ONE block (0: Adam over the stacked cameras + orientations, 1: Adam over the shared pose / betas; a fresh optimiser) of
+ * cfg->iters epochs from the given state, WITHOUT record keeping: in place the block's LAST iterate; val_l2e [B,iters] the mean
+ * joints2D_l2es of every epoch's validation pass; snap_views [B,iters,V,12] ([cam | orientation] per view) and snap_shared
+ * [B,iters,217] ([body pose (207) | betas]) the parameters every epoch's validation pass saw.  For the reference's record rule over
+ * BOTH tracked metrics (determine_save_model_weights_this_epoch with joints2D_l2es and the rendered-silhouette metric,
+ * PR/player_recon.py:1820, 1937): the caller renders the snapshots, decides, and starts the next block from the block's best epoch
+ * (Python: player_recon.multi_view_optimization(select_mode='reference')).  view_order: [iters][V] or NULL. */
+int spsp_fit_multiview_block(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int block, int B, int V, float* body_pose,
+                             float* betas, float* cam, float* global_orient, const float* joints2d, const int32_t* view_order,
+                             float* val_l2e, float* snap_views, float* snap_shared, void* stream);
 
 /* ---- exchange step without torch: ONE RCCL all-gather of the packed records over xGMI, for hosts that
  *      drive this library directly.  Rank 0 calls spsp_comm_unique_id and ships the 128 bytes to the other ranks

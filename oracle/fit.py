@@ -112,3 +112,33 @@ def fit_pose_shape(smpl, body_pose, global_orient, betas, joints2D, cam_wp, lr=1
             record.setdefault('betas', []).append(s[2].numpy())
             record.setdefault('cam', []).append(s[3].numpy())
     return {'last': snapshot(), 'best': best, 'best_l2e': best_l2e}
+
+
+def fit_broad_view(smpl, body_pose, global_orient, betas, joints2D, cam_wp, lr=1e-2, iters=100, silhouette_metric=None):
+    """`broad_view_optimization` (`PR/player_recon.py:2128-2229`) for ONE player: Adam([cam_wp, global_orient]); every epoch a
+    train pass (step) then a validation pass on the stepped parameters; an epoch is saved iff its validation joints2D_l2es --
+    and, when `silhouette_metric(vertices [6890,3], cam_wp [3]) -> float` is given, that metric too -- is <= its value at the
+    previous save (`determine_save_model_weights_this_epoch`).  Returns dict(best=(G, cam), best_epoch (1-based), val_l2e, val_sil)."""
+    global_orient = global_orient.detach().clone().requires_grad_(True)
+    cam_wp = cam_wp.detach().clone().requires_grad_(True)
+    optimiser = optim.Adam([cam_wp, global_orient], lr=lr)
+    target = torch.from_numpy(np.asarray(joints2D)[:, :2]).float()
+    best, best_epoch, bl, bs = (global_orient.detach().clone(), cam_wp.detach().clone()), 0, np.inf, np.inf
+    val_l2e, val_sil = [], []
+    for epoch in range(1, iters + 1):
+        for is_train in (True, False):
+            out = smpl(body_pose=body_pose, global_orient=global_orient, betas=betas, pose2rot=False)
+            pred = _project17(out, cam_wp)
+            if is_train:
+                optimiser.zero_grad()
+                joints2d_loss(pred[0], target).backward()
+                optimiser.step()
+            else:
+                l2e = joints2d_l2e(pred[0].detach().numpy(), target.numpy())
+                sm = silhouette_metric(out.vertices[0].detach().numpy(), cam_wp[0].detach().numpy()) if silhouette_metric else 0.0
+                val_l2e.append(l2e)
+                val_sil.append(sm)
+                if not (l2e > bl) and not (silhouette_metric is not None and sm > bs):
+                    bl, bs, best_epoch = l2e, sm, epoch
+                    best = (global_orient.detach().clone(), cam_wp.detach().clone())
+    return {'best': best, 'best_epoch': best_epoch, 'val_l2e': np.asarray(val_l2e), 'val_sil': np.asarray(val_sil)}

@@ -20,9 +20,9 @@ real `torch.autograd` + `torch.optim.Adam`:
   :1954-1957    betas_mean = best_betas_mean; body_poses_without_hands_feet = best_pose
   :1976-1979    saved: body_pose / betas of the record, translation / global_orient of every view
 
-Deviations, both stated in csrc/fit_mv_core.hpp as well: views are visited in the order 0..V-1 (the reference calls
-`random.shuffle` before every pass); the record is decided by joints2D_l2es alone (the reference also tracks a
-rasterised-silhouette metric).  If a pose block never reaches the record the reference reads
+By default the views are visited in the order 0..V-1 and the record is decided by joints2D_l2es alone; `view_orders` takes the
+orders the reference draws with `random.shuffle` before every pass, `silhouette_metric` adds the second tracked metric of its
+record rule.  If a pose block never reaches the record the reference reads
 `best_betas_mean` before assignment in round 0 (NameError) and a stale copy later; here the block's parameters return
 to their values at the block's start, which is what the stale copy holds from round 1 on."""
 import numpy as np
@@ -34,7 +34,7 @@ from .geometry import joints2d_l2e, joints2d_loss, translation_to_wp, wp_to_tran
 
 
 def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, translation_views, joints2D_views, lr=1e-3,
-                   iters=50, rounds=3, stale_pose_cat=True, record=None):
+                   iters=50, rounds=3, stale_pose_cat=True, record=None, view_orders=None, silhouette_metric=None):
     """ONE player.  body_pose_views [V,1,23,3,3], global_orient_views [V,1,1,3,3], betas_views [V,1,10],
     translation_views [V,1,3] (torch fp32), joints2D_views [V,17,>=2] numpy.  Returns dict(body_pose [1,23,3,3],
     betas [1,10], translation [V,1,3], global_orient [V,1,1,3,3], cam_wp [V,1,3], best_val, val_history)."""
@@ -47,7 +47,8 @@ def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, tran
     betas_mean = torch.stack([betas_views[j] for j in range(V)]).mean(axis=0).detach().clone()                   # [1,10]
 
     best_pose = torch.cat([body_pose_mean[:, :6], body_pose_mean[:, 8:21]], dim=1)
-    best_val = np.inf
+    best_val, best_sil = np.inf, np.inf
+    sil_history = []
     best_model_wts = [body_pose_mean.detach().numpy().copy(), betas_mean.detach().numpy().copy()]
     best_model_view = [[translation_mult[j].detach().numpy().copy(), global_orient_mult[j].detach().numpy().copy()] for j in range(V)]
     best_cam_view = [cam_wp_mult[j].detach().numpy().copy() for j in range(V)]
@@ -70,9 +71,10 @@ def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, tran
         optimiser = optim.Adam([cam_wp_mult, global_orient_mult], lr=lr)
         best_cam_wp_mult, best_global_orient_mult = cam_wp_mult.clone().detach(), global_orient_mult.clone().detach()
         for epoch in range(iters):
-            val = 0.0
+            val, silv = 0.0, 0.0
             for is_train in (True, False):
-                for index in order:
+                for index in (view_orders[(i * 2 + 0) * iters + epoch] if (view_orders is not None and is_train) else order):
+                    index = int(index)
                     out = smpl(body_pose=body_poses_with_hand_feet, global_orient=global_orient_mult[index], betas=betas_mean,
                                pose2rot=False)
                     pred = _project17(out, cam_wp_mult[index])
@@ -84,10 +86,14 @@ def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, tran
                         translation_mult[index] = wp_to_translation(cam_wp_mult[index]).detach()
                     else:
                         val += joints2d_l2e(pred[0].detach().numpy(), targets[index].numpy())
+                        if silhouette_metric is not None:
+                            silv += silhouette_metric(index, out.vertices[0].detach().numpy(), cam_wp_mult[index][0].detach().numpy())
             val /= V
+            silv /= V
             history.append(val)
-            if not (val > best_val):
-                best_val = val
+            sil_history.append(silv)
+            if not (val > best_val) and not (silhouette_metric is not None and silv > best_sil):
+                best_val, best_sil = val, silv
                 best_model_wts = [body_poses_with_hand_feet.detach().numpy().copy(), betas_mean.detach().numpy().copy()]
                 for j in range(V):
                     best_model_view[j] = [translation_mult[j].detach().numpy().copy(), global_orient_mult[j].detach().numpy().copy()]
@@ -112,9 +118,10 @@ def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, tran
         best_betas_mean = betas_mean.clone().detach()
         best_pose = body_poses_without_hands_feet.clone().detach()
         for epoch in range(iters):
-            val = 0.0
+            val, silv = 0.0, 0.0
             for is_train in (True, False):
-                for index in order:
+                for index in (view_orders[(i * 2 + 1) * iters + epoch] if (view_orders is not None and is_train) else order):
+                    index = int(index)
                     posed = body_poses_with_hand_feet if stale_pose_cat else assemble(body_poses_without_hands_feet)
                     out = smpl(body_pose=posed, global_orient=global_orient_mult[index], betas=betas_mean, pose2rot=False)
                     pred = _project17(out, cam_wp_mult[index])
@@ -125,10 +132,14 @@ def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, tran
                         optimiser_pose.step()
                     else:
                         val += joints2d_l2e(pred[0].detach().numpy(), targets[index].numpy())
+                        if silhouette_metric is not None:
+                            silv += silhouette_metric(index, out.vertices[0].detach().numpy(), cam_wp_mult[index][0].detach().numpy())
             val /= V
+            silv /= V
             history.append(val)
-            if not (val > best_val):
-                best_val = val
+            sil_history.append(silv)
+            if not (val > best_val) and not (silhouette_metric is not None and silv > best_sil):
+                best_val, best_sil = val, silv
                 posed = body_poses_with_hand_feet if stale_pose_cat else assemble(body_poses_without_hands_feet)
                 best_model_wts = [posed.detach().numpy().copy(), betas_mean.detach().numpy().copy()]
                 for j in range(V):
@@ -141,4 +152,5 @@ def fit_multi_view(smpl, body_pose_views, global_orient_views, betas_views, tran
         betas_mean = best_betas_mean
     return {'body_pose': best_model_wts[0], 'betas': best_model_wts[1],
             'translation': np.stack([b[0] for b in best_model_view]), 'global_orient': np.stack([b[1] for b in best_model_view]),
-            'cam_wp': np.stack(best_cam_view), 'best_val': best_val, 'val_history': np.asarray(history, np.float32)}
+            'cam_wp': np.stack(best_cam_view), 'best_val': best_val, 'val_history': np.asarray(history, np.float32),
+            'best_sil': best_sil, 'sil_history': np.asarray(sil_history, np.float64)}

@@ -200,8 +200,10 @@ def project_torch(verts, translation, focal=FOCAL_LENGTH, wh=PROXY_REP_INPUT_WH)
     x, y, z = v[:, 0], v[:, 1], v[:, 2]
     xd, yd = x / (z + 1e-9), y / (z + 1e-9)
     half = 0.5 * wh
-    u = focal * xd + half
-    vv = wh - (focal * yd + half)
+    # K applied as ONE fused multiply-add per coordinate (oracle/silhouette.py `project` and the kernels do the same): through
+    # float64, rounded once -- coverage decisions and the backward pass's pixel distances hang on the last bit of these
+    u = (xd.double() * focal + half).float()
+    vv = wh - (yd.double() * focal + half).float()
     return torch.stack([2 * (u - half) / wh, 2 * (vv - half) / wh, z], dim=-1)
 
 

@@ -24,8 +24,9 @@ OK, EINVAL, ENOMEM, EHIP, ENCCL = 0, -1, -2, -3, -4           # include/spsp.h s
 PROXY_NCHW_F32, PROXY_NATIVE = 0, 1
 PRECISION_BF16, PRECISION_F16 = 0, 1
 SIL_U8, SIL_F32 = 0, 1
-DEBUG_IEF_STALL, DEBUG_PLAN_S2, DEBUG_PLAN_LAYER4_CHANNELS = 1, 2, 3
+DEBUG_IEF_STALL, DEBUG_PLAN_S2, DEBUG_PLAN_LAYER4_CHANNELS, DEBUG_PLAN_PATCH = 1, 2, 3, 4
 REGRESSOR_MAX_BATCH, REGRESSOR_MAX_CONCURRENT = 256, 8
+PLAN_THROUGHPUT, PLAN_LATENCY = 0, 1
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -67,6 +68,12 @@ class FitMultiviewConfig(C.Structure):
     _fields_ = [('iters', C.c_int), ('rounds', C.c_int), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
                 ('eps', C.c_double), ('loss_weight', C.c_double), ('img_wh', C.c_float), ('loss_wh', C.c_float),
                 ('optimise_body_pose', C.c_int)]
+
+
+class FitSilhouetteConfig(C.Structure):
+    _fields_ = [('iters', C.c_int), ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
+                ('joints2d_weight', C.c_double), ('silhouette_weight', C.c_double), ('param_mask', C.c_uint32),
+                ('img_wh', C.c_float), ('loss_wh', C.c_float), ('focal', C.c_float)]
 
 
 class PipelineOut(C.Structure):
@@ -141,6 +148,7 @@ _PROTOS = {
     'spsp_regressor_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spsp_regressor_read_stage': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_status': (C.c_int, [_vp]),
+    'spsp_regressor_set_plan': (C.c_int, [_vp, C.c_int]),
     'spsp_regressor_debug': (C.c_int, [_vp, C.c_int, C.c_int]),
     'spsp_rot6d_to_rotmat': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     'spsp_project': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp]),
@@ -156,9 +164,17 @@ _PROTOS = {
     'spsp_rasterizer_load': (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     'spsp_rasterizer_free': (None, [_vp]),
     'spsp_render_silhouettes': (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
+    'spsp_silhouette_loss_grad': (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'spsp_smpl_vertices_vjp': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    'spsp_fit_silhouette_config_default': (None, [C.POINTER(FitSilhouetteConfig)]),
+    'spsp_fit_silhouette': (C.c_int, [_vp, _vp, _vp, C.POINTER(FitSilhouetteConfig), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp,
+                                      _vp, _vp, _vp]),
     'spsp_fit_select': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'spsp_fit_multiview_config_default': (None, [C.POINTER(FitMultiviewConfig)]),
     'spsp_fit_multiview': (C.c_int, [_vp, _vp, C.POINTER(FitMultiviewConfig), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'spsp_fit_multiview_ordered': (C.c_int, [_vp, _vp, C.POINTER(FitMultiviewConfig), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'spsp_fit_multiview_block': (C.c_int, [_vp, _vp, C.POINTER(FitMultiviewConfig), C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -25,3 +25,5 @@ player_recon_multi_view_iteration = 50       # S/global_var.py:79
 texture_single_opt_interation = 50
 optimize_camera_learning_rate = 0.01
 optimize_camera_iterations = 50
+player_recon_broad_view_iteration = 100          # S/global_var.py:83
+player_recon_broad_view_learning_rate = 1e-2     # S/global_var.py:84

@@ -22,6 +22,12 @@ struct MvArgs {
     float* G;               // [B][V][9]    in / out
     const float* joints2d;  // [B][V][17][2]
     float* val_hist;        // [B][rounds * 2 * iters] or NULL
+    const int* view_order;  // [rounds * 2 * iters][V] view visited at each train step of each epoch, or NULL (0 .. V-1)
+    // single-block mode (only_block >= 0): ONE block of `iters` epochs from the given state, no record keeping -- every epoch's
+    // parameters are written out instead (the reference's two-metric record rule is applied outside, spsp_fit_multiview_block)
+    int only_block;
+    float* snap_views;      // [B][iters][V][12]
+    float* snap_shared;     // [B][iters][217]  body pose (207) | betas (10)
 };
 
 __global__ __launch_bounds__(spsp::kFitLanes) void fit_multiview_kernel(const MvArgs a) {
@@ -66,12 +72,14 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_multiview_kernel(const Mv
     fit_p11(s, r, lane); __syncthreads();
 
     for (int round = 0; round < a.rounds; ++round)
-        for (int block = 0; block < 2; ++block) {
+        for (int block = a.only_block >= 0 ? a.only_block : 0; block < (a.only_block >= 0 ? a.only_block + 1 : 2); ++block) {
             mv_block_start(s, m, r, lane, block, V, a.mask_shared);
             __syncthreads();
             double b1t = 1.0, b2t = 1.0;
             for (int ep = 0; ep < P.iters; ++ep) {
-                for (int v = 0; v < V; ++v) {                 // ---- train: one optimiser step per view
+                const int* ord = a.view_order ? a.view_order + (size_t)((round * 2 + (a.only_block >= 0 ? 0 : block)) * P.iters + ep) * V : nullptr;
+                for (int vi = 0; vi < V; ++vi) {              // ---- train: one optimiser step per view
+                    const int v = ord ? ord[vi] : vi;
                     b1t *= P.beta1;
                     b2t *= P.beta2;
                     const float step_size = (float)(P.lr / (1.0 - b1t));
@@ -91,14 +99,31 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_multiview_kernel(const Mv
                     mv_val_add(s, m, lane, v == 0);
                     __syncthreads();
                 }
+                if (a.only_block >= 0) {                      // no record here: the epoch's validation metric and parameters go out
+                    if (lane == 0 && vh) vh[ep] = m.val_acc / (float)V;
+                    if (lane < V * kViewPrm) a.snap_views[((size_t)b * P.iters + ep) * V * kViewPrm + lane] = m.vprm[lane];
+                    if (lane < 217) a.snap_shared[((size_t)b * P.iters + ep) * 217 + lane] = s.prm[kPrmR + 9 + lane];
+                    __syncthreads();
+                    continue;
+                }
                 mv_epoch_decide(m, lane, V, vh, (round * 2 + block) * P.iters + ep);
                 __syncthreads();
                 mv_epoch_snapshot(s, m, lane, block, V);
                 __syncthreads();
             }
-            mv_block_end(s, m, lane, block, V);
+            if (a.only_block < 0) mv_block_end(s, m, lane, block, V);
             __syncthreads();
         }
+    if (a.only_block >= 0) {                                  // the LAST iterate of the block
+        if (lane < 207) a.body[(size_t)b * 207 + lane] = s.prm[kPrmR + 9 + lane];
+        if (lane < 10) a.betas[(size_t)b * 10 + lane] = s.prm[kPrmBeta + lane];
+        if (lane < V * kViewPrm) {
+            const int u = lane / kViewPrm, p = lane - u * kViewPrm;
+            if (p < 3) a.cam[((size_t)b * V + u) * 3 + p] = m.vprm[lane];
+            else a.G[((size_t)b * V + u) * 9 + (p - 3)] = m.vprm[lane];
+        }
+        return;
+    }
 #undef MV_BACKWARD
 #undef MV_FORWARD
     // what the reference saves (:1976-1979): the record's shared pose / betas and every view's camera / orientation
@@ -126,8 +151,9 @@ void spsp_fit_multiview_config_default(spsp_fit_multiview_config* c) {
     c->optimise_body_pose = 0;     // the reference's block 2 moves betas only (fit_mv_core.hpp)
 }
 
-int spsp_fit_multiview(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose,
-                       float* betas, float* cam, float* global_orient, const float* joints2d, float* val_hist, void* stream) {
+static int fit_multiview_launch(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose, float* betas,
+                                float* cam, float* global_orient, const float* joints2d, const int32_t* view_order, float* val_hist,
+                                int only_block, float* snap_views, float* snap_shared, void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && s && cfg, "spsp_fit_multiview: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));
@@ -146,15 +172,35 @@ int spsp_fit_multiview(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_con
     a.P.weight = std::exp(-a.P.log_var);
     a.P.select_mode = SPSP_FIT_SELECT_LAST;
     a.P.num_levels = s->num_levels;
-    a.V = V; a.rounds = cfg->rounds;
+    a.V = V; a.rounds = only_block >= 0 ? 1 : cfg->rounds;
     a.mask_shared = SPSP_FIT_BETAS | (cfg->optimise_body_pose ? 0x003FFE7Eu : 0u);
     a.fitc = s->fitc; a.parents = s->parents; a.level_joints = s->level_joints; a.level_start = s->d_level_start;
     a.child_start = s->child_start; a.child_list = s->child_list;
     a.body = body_pose; a.betas = betas; a.cam = cam; a.G = global_orient; a.joints2d = joints2d; a.val_hist = val_hist;
+    a.view_order = view_order; a.only_block = only_block; a.snap_views = snap_views; a.snap_shared = snap_shared;
     ProfScope ps(ctx, kKFit, as_stream(stream));
     fit_multiview_kernel<<<B, kFitLanes, 0, as_stream(stream)>>>(a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
+}
+
+int spsp_fit_multiview(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose,
+                       float* betas, float* cam, float* global_orient, const float* joints2d, float* val_hist, void* stream) {
+    return fit_multiview_launch(ctx, s, cfg, B, V, body_pose, betas, cam, global_orient, joints2d, nullptr, val_hist, -1, nullptr, nullptr, stream);
+}
+
+int spsp_fit_multiview_ordered(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int B, int V, float* body_pose,
+                               float* betas, float* cam, float* global_orient, const float* joints2d, const int32_t* view_order,
+                               float* val_hist, void* stream) {
+    return fit_multiview_launch(ctx, s, cfg, B, V, body_pose, betas, cam, global_orient, joints2d, view_order, val_hist, -1, nullptr, nullptr, stream);
+}
+
+int spsp_fit_multiview_block(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_multiview_config* cfg, int block, int B, int V, float* body_pose,
+                             float* betas, float* cam, float* global_orient, const float* joints2d, const int32_t* view_order,
+                             float* val_l2e, float* snap_views, float* snap_shared, void* stream) {
+    SPSP_REQUIRE(block == 0 || block == 1, "spsp_fit_multiview_block: block %d (0: cameras + orientations, 1: shared pose / betas)", block);
+    SPSP_REQUIRE(B == 0 || (snap_views && snap_shared), "spsp_fit_multiview_block: NULL snapshot buffer");
+    return fit_multiview_launch(ctx, s, cfg, B, V, body_pose, betas, cam, global_orient, joints2d, view_order, val_l2e, block, snap_views, snap_shared, stream);
 }
 
 }  // extern "C"

@@ -448,8 +448,11 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // 128-pixel tiles where 256-pixel ones cover half (layer3: 128) or a quarter (layer4: 64) of the 256 CUs
         const int def_tile[4] = {256, 256, 128, 128};
         const int def_ring[4] = {3, 3, 3, 3};
-        // layer4 in 32-channel blocks: 256 workgroups instead of 128, 488 KB instead of 776 KB staged per workgroup
-        const int def_nch[4] = {64, 64, 64, 32};
+        // layer4: 64-channel blocks (128 workgroups) for throughput -- with several batches in flight what counts is the CU time a
+        // launch consumes, and 256 workgroups of 32 channels stage the input patch twice as often (A/B in one process,
+        // tools/ab_pipeline.py: 116.0 k vs 113.4 k players/s); a single batch in flight finishes sooner on 256 workgroups
+        // (18.9 -> 13.2 us per launch, tools/ab_plan.py): spsp_regressor_set_plan(SPSP_PLAN_LATENCY)
+        const int def_nch[4] = {64, 64, 64, 64};
         for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; }
 #if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
@@ -589,6 +592,13 @@ int spsp_regressor_status(spsp_regressor* r) {
     return SPSP_EHIP;
 }
 
+int spsp_regressor_set_plan(spsp_regressor* r, int plan) {
+    SPSP_REQUIRE(r, "spsp_regressor_set_plan: NULL handle");
+    SPSP_REQUIRE(plan == SPSP_PLAN_THROUGHPUT || plan == SPSP_PLAN_LATENCY, "spsp_regressor_set_plan: unknown plan %d", plan);
+    r->patch_nch[3] = plan == SPSP_PLAN_LATENCY ? 32 : 64;
+    return SPSP_OK;
+}
+
 int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
     SPSP_REQUIRE(r, "spsp_regressor_debug: NULL handle");
     switch (what) {
@@ -598,6 +608,12 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             SPSP_REQUIRE(value == 32 || value == 64, "spsp_regressor_debug: layer4 blocks of %d channels", value);
             r->patch_nch[3] = value;
             return SPSP_OK;
+        case SPSP_DEBUG_PLAN_PATCH: {       // value = layer * 10000 + tile_pixels * 10 + ring_groups * 2 + two_patch_buffers
+            const int L = value / 10000, tile = (value % 10000) / 10, ring = (value % 10) / 2, db = value & 1;
+            SPSP_REQUIRE(L >= 1 && L <= 3 && (tile == 128 || tile == 256) && (ring == 2 || ring == 3), "spsp_regressor_debug: patch plan %d", value);
+            r->patch_tile[L] = tile; r->patch_ring[L] = ring; r->patch_db[L] = db != 0;
+            return SPSP_OK;
+        }
         default: break;
     }
     spsp::set_error("spsp_regressor_debug: unknown hook %d", what);

@@ -17,8 +17,8 @@
 //            -sum_px [ p ln(t + 1e-6) + (1 - p) ln(1 - t + 1e-6) ],  p = rendered, t = detected silhouette.
 //   rule     an iterate is the new best iff joints2D_l2es AND this metric are both <= their values at the previous
 //            best (determine_save_model_weights_this_epoch, :291-298; use at PR/player_recon.py:1259-1271).
-// Not built: neural_renderer's approximate BACKWARD pass (only `single_view_optimization_test`, :1429, puts the
-// silhouette into the loss; the production fits track it as a metric only).
+// The differentiable half -- neural_renderer's approximate BACKWARD pass and the loss of `single_view_optimization_test`
+// (:1429) -- is silhouette_grad.hip.
 //
 // Kernels: a workgroup = (mesh, strip of 128 sample rows): it projects the vertices into LDS, walks ALL faces (bounding box
 // of samples clipped to its strip, the inequality test above) and ORs the covered samples into its strip's bit mask IN LDS
@@ -29,6 +29,7 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "silhouette.hpp"
 
 namespace {
 using namespace spsp;
@@ -207,14 +208,6 @@ __global__ void select_kernel(const float* __restrict__ l2e, const float* __rest
 
 }  // namespace
 
-struct spsp_rasterizer {
-    spsp::DevicePool pool;
-    int* faces;
-    int F, max_batch, wh;
-    unsigned int* mask;      // [max_batch][(2 wh)^2 / 32]
-    float* partial;          // [max_batch][ceil(wh^2 / 256)]
-};
-
 extern "C" {
 
 int spsp_rasterizer_load(spsp_ctx* ctx, const int32_t* faces, int F, int max_batch, int img_wh, spsp_rasterizer** out) {
@@ -225,6 +218,7 @@ int spsp_rasterizer_load(spsp_ctx* ctx, const int32_t* faces, int F, int max_bat
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));
     spsp_rasterizer* h = new spsp_rasterizer;
     h->F = F; h->max_batch = max_batch; h->wh = img_wh;
+    h->host_faces.assign(faces, faces + (size_t)3 * F);
     int rc = h->pool.upload(&h->faces, faces, (size_t)3 * F);
     if (rc == SPSP_OK) rc = h->pool.alloc(&h->mask, (size_t)max_batch * (4 * (size_t)img_wh * img_wh / 32));
     if (rc == SPSP_OK) rc = h->pool.alloc(&h->partial, (size_t)max_batch * ((img_wh * img_wh + 255) / 256));

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
                                                                  const float* __restrict__ wT,
                                                                  const float* __restrict__ A,
                                                                  const float* __restrict__ coef, int B,
-                                                                 float* __restrict__ verts) {
+                                                                 float* __restrict__ verts, float* __restrict__ vposed) {
     __shared__ float sCoef[kPB][kNCoef + 3];
     __shared__ __attribute__((aligned(16))) float sA[kPB][288];
     __shared__ float sPart[4][kPB * 3][64];                // [k-slice][player*3 + c][lane]
@@ -122,6 +122,11 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
         qy[q] = t1 + ((sPart[0][p * 3 + 1][lane] + sPart[1][p * 3 + 1][lane]) + (sPart[2][p * 3 + 1][lane] + sPart[3][p * 3 + 1][lane]));
         qz[q] = t2 + ((sPart[0][p * 3 + 2][lane] + sPart[1][p * 3 + 2][lane]) + (sPart[2][p * 3 + 2][lane] + sPart[3][p * 3 + 2][lane]));
         ox[q] = oy[q] = oz[q] = 0.f;
+        // (the differentiable path keeps the posed rest vertex: d vertex / d A_k needs it, smpl_vjp.hip)
+        if (vposed && p < nb && blockIdx.x * 64 + lane < kV) {
+            float* o = vposed + ((size_t)(b0 + p) * kV + v) * 3;
+            o[0] = qx[q]; o[1] = qy[q]; o[2] = qz[q];
+        }
     }
 #pragma unroll 4
     for (int k = 0; k < kNJ; ++k) {
@@ -225,7 +230,15 @@ void spsp_smpl_free(spsp_smpl* s) { delete s; }
 
 int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B, float* verts,
                       float* joints, void* stream) {
-    using namespace spsp;
+    return spsp::smpl_forward_impl(ctx, s, R, betas, B, verts, joints, nullptr, stream);
+}
+
+}  // extern "C"
+
+namespace spsp {
+// vposed: optional [B,6890,3] -- the posed REST vertices (template + blend shapes) the skinning multiplies, kept for the VJP
+int smpl_forward_impl(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B, float* verts, float* joints,
+                      float* vposed, void* stream) {
     SPSP_REQUIRE(ctx && s, "spsp_smpl_forward: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     if (B == 0) return SPSP_OK;          // empty batch: nothing to do (pointers of empty tensors may be NULL)
@@ -240,7 +253,7 @@ int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
     float* v = verts ? verts : s->ws_verts;
     dim3 grid((kV + 63) / 64, (B + kPB - 1) / kPB);
     { ProfScope ps(ctx, kKSmplSkin, st, true);
-      launch_kernel(&smpl_skin_kernel, grid, dim3(kSkinThreads), 0, st, s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v); }
+      launch_kernel(&smpl_skin_kernel, grid, dim3(kSkinThreads), 0, st, s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v, vposed); }
     SPSP_HIP_CHECK(hipGetLastError());
     if (joints) {
         ProfScope ps(ctx, kKSmplJoints, st, true);
@@ -250,4 +263,5 @@ int spsp_smpl_forward(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
     return SPSP_OK;
 }
 
-}  // extern "C"
+}  // namespace spsp
+

@@ -32,4 +32,21 @@ struct spsp_smpl {
     float* ws_coef;      // [max_batch][217]
     float* ws_verts;     // [max_batch][6890][3] (only used when the caller passes verts == NULL)
     int host_parents[24];
+    // differentiable path (smpl_vjp.hip, fit_sil.hip), allocated at first use
+    float* ws_vposed = nullptr;  // [max_batch][6890][3]
+    float* ws_dvp = nullptr;     // [max_batch][6890][3]   dL/d(posed rest vertex)
+    float* ws_seedp = nullptr;   // [max_batch][27][288]   chunk partials of the per-joint seeds
+    float* ws_seeds = nullptr;   // [max_batch][24][12]    rows [S1_k[i][0..2] | S0_k[i]]
+    float* ws_gcoef = nullptr;   // [max_batch][217]       basis . dvp
+    float* ws_gverts = nullptr;  // [max_batch][6890][3]
+    float* ws_adam = nullptr;    // [max_batch][2][232]    Adam moments of the silhouette fit
+    float* ws_misc = nullptr;    // [max_batch][16]        translation(3) | grad_translation(3) | sil_sum | weight | ...
 };
+
+namespace spsp {
+int smpl_forward_impl(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B, float* verts, float* joints,
+                      float* vposed, void* stream);
+int smpl_vjp_workspace(spsp_smpl* s);
+// grad_verts [B,6890,3] -> seeds + gcoef workspaces of the handle (needs a forward with vposed for the same R / betas before it)
+int smpl_vjp_seeds(spsp_ctx* ctx, spsp_smpl* s, const float* grad_verts, int B, void* stream);
+}

@@ -23,12 +23,16 @@ def _np(a):
 
 class SingleInputRegressor:
     def __init__(self, resnet_in_channels=18, resnet_layers=18, ief_iters=3, mean_params=None, max_batch=32,
-                 precision='f16'):
+                 precision='f16', plan='throughput'):
         if resnet_in_channels != 18 or resnet_layers != 18:
             raise NotImplementedError('only the configuration the reference ever instantiates is built: '
                                       'SingleInputRegressor(18, 18, 3) (PR/player_recon.py:134-136)')
         self.ief_iters = ief_iters
         self.max_batch = max_batch
+        # launch plan (include/spsp.h): 'throughput' for several batches in flight (PlayerPipeline), 'latency' for one
+        if plan not in ('throughput', 'latency'):
+            raise ValueError(f"plan must be 'throughput' or 'latency', got {plan!r}")
+        self.plan = plan
         # storage / MFMA element type of the backbone (include/spsp.h): 'f16' (default; precision 1) keeps the END-TO-END
         # vertices within 1e-3 m of the all-fp32 reference path; 'bf16' (precision 0) has the same bytes and MFMA rate but
         # 3 mantissa bits fewer (~1.5e-3 m)
@@ -127,6 +131,7 @@ class SingleInputRegressor:
         with torch.cuda.device(r.device):
             r.check(lib.spsp_regressor_load(r.ctx, C.byref(w), self.max_batch, self._prec, C.byref(h)), 'spsp_regressor_load')
         self._handle, self._rt = h, r
+        self.set_plan(self.plan)
 
     # -- forward ------------------------------------------------------------------------------------
     def pack(self, proxy_nchw):
@@ -160,6 +165,15 @@ class SingleInputRegressor:
     @property
     def handle(self):
         return self._handle
+
+    def set_plan(self, plan):
+        if plan not in ('throughput', 'latency'):
+            raise ValueError(f"plan must be 'throughput' or 'latency', got {plan!r}")
+        self.plan = plan
+        if self._handle is not None:
+            self._rt.check(self._rt.lib.spsp_regressor_set_plan(self._handle, _abi.PLAN_LATENCY if plan == 'latency' else _abi.PLAN_THROUGHPUT),
+                           'spsp_regressor_set_plan')
+        return self
 
     def check_status(self):
         """Raises RuntimeError if a kernel of an earlier forward on this handle reported a device-side failure (the fused

@@ -134,3 +134,22 @@ class SMPL:
         return SMPLOutput(vertices=verts, joints=joints, betas=betas, body_pose=bp, global_orient=go, full_pose=full_pose)
 
     __call__ = forward
+
+    def vertices_vjp(self, full_pose, betas, grad_vertices):
+        """Reverse mode of `forward(...).vertices` (what `loss.backward()` does to the mesh in the reference's silhouette fit,
+        `PR/player_recon.py:1429-1537`): full_pose [B,24,3,3], betas [B,10], grad_vertices [B,6890,3] -> (grad_full_pose
+        [B,24,3,3], grad_betas [B,10])."""
+        if self._handle is None:
+            self._load(rt.get(grad_vertices.device if isinstance(grad_vertices, torch.Tensor) and grad_vertices.is_cuda else None))
+        r = self._rt
+        betas = rt.dev_f32(betas, r.device).reshape(-1, 10)
+        B = betas.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f'SMPL.vertices_vjp: batch {B} exceeds max_batch {self.max_batch}')
+        R = rt.dev_f32(full_pose, r.device).reshape(B, 24, 3, 3).contiguous()
+        g = rt.dev_f32(grad_vertices, r.device).reshape(B, 6890, 3).contiguous()
+        gR = torch.empty((B, 24, 3, 3), dtype=torch.float32, device=r.device)
+        gb = torch.empty((B, 10), dtype=torch.float32, device=r.device)
+        r.check(r.lib.spsp_smpl_vertices_vjp(r.ctx, self.handle, rt.ptr(R), rt.ptr(betas), B, rt.ptr(g), rt.ptr(gR), rt.ptr(gb), r.stream()),
+                'spsp_smpl_vertices_vjp')
+        return gR, gb

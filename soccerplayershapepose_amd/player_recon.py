@@ -126,8 +126,120 @@ def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp,
     return SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam, **extra)
 
 
+def broad_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp, joints2D, interation=None, lr=None,
+                            select_mode=_abi.FIT_SELECT_BEST_L2E, silhouette=None, renderer=None):
+    """Fit body of `broad_view_optimization` (`PR/player_recon.py:2128-2229`): the shared body pose and betas (the multi-view
+    result) stay fixed; the broadcast view's camera and global orientation (initialised by the regressor on that view) are
+    fitted with `Adam([pred_cam_wp, global_orient], lr=1e-2)` for 100 epochs (`S/global_var.py:83-84`).  Unlike the single-view
+    loop every epoch has a TRAIN pass (loss, backward, step) and then a VALIDATION pass on the stepped parameters; the epoch
+    whose validation metrics are the best so far is saved (`:2207-2221`) -- so the candidates are the parameters AFTER steps
+    1..N, not the ones each step started from.
+    select_mode: FIT_SELECT_BEST_L2E (validation joints2D_l2es alone), FIT_SELECT_REFERENCE (the reference's rule over both
+    tracked metrics, joints2D_l2es AND the rendered-silhouette metric: needs silhouette= and renderer=), FIT_SELECT_LAST.
+    Returns the record the reference saves (`:2207-2211`): body_pose, global_orient [B,1,3,3], betas, translation, plus cam_wp and
+    best_epoch [B] (1-based).  Inputs are not modified."""
+    B = betas.shape[0]
+    full = torch.cat([rt.dev_f32(global_orient).reshape(B, 1, 3, 3), rt.dev_f32(body_pose).reshape(B, 23, 3, 3)], dim=1).contiguous()
+    r = rt.get(full.device)
+    b = rt.dev_f32(betas, r.device).clone()
+    cam = rt.dev_f32(pred_cam_wp, r.device).clone()
+    iters = int(interation if interation is not None else config.player_recon_broad_view_iteration)
+    lr = float(lr if lr is not None else config.player_recon_broad_view_learning_rate)
+    # iters + 1 evaluation points: point i >= 1 = the parameters after step i = what epoch i's validation pass sees
+    loss, l2e, traj = fit_players(smpl, full, b, cam, joints2D, variant=0, iters=iters + 1, lr=lr, select_mode=_abi.FIT_SELECT_LAST,
+                                  return_trajectory=True)
+    l2e_val, traj_val = l2e[:, 1:].contiguous(), traj[:, 1:].contiguous()
+    best_iter = torch.full((B,), iters - 1, dtype=torch.int32, device=r.device)
+    sil = None
+    if select_mode == FIT_SELECT_REFERENCE:
+        if silhouette is None or renderer is None:
+            raise ValueError('broad_view_optimization: select_mode "reference" needs silhouette= [B,512,512] and renderer=')
+        wh = config.proxy_rep_input_wh
+        tgt = torch.as_tensor(silhouette).to(device=r.device, dtype=torch.uint8).reshape(B, wh, wh).contiguous()
+        sil = torch.empty((B, iters), dtype=torch.float32, device=r.device)
+        for it in range(iters):
+            rec = traj_val[:, it]
+            verts = smpl(full_pose=rec[:, 3:219].reshape(B, 24, 3, 3).contiguous(), betas=rec[:, 219:].contiguous(), return_joints=False).vertices
+            t_it = convert_weak_perspective_to_camera_translation_torch(rec[:, :3].contiguous(), config.FOCAL_LENGTH, wh)
+            sil[:, it] = renderer(verts, t_it, target=tgt, return_image=False).metric
+    if select_mode == _abi.FIT_SELECT_LAST:
+        rec = traj_val[:, -1]
+        full, b, cam = rec[:, 3:219].reshape(B, 24, 3, 3).contiguous(), rec[:, 219:].contiguous(), rec[:, :3].contiguous()
+    else:
+        r.check(r.lib.spsp_fit_select(r.ctx, rt.ptr(l2e_val), rt.ptr(sil), iters, B, rt.ptr(traj_val), rt.ptr(full), rt.ptr(b), rt.ptr(cam),
+                                      rt.ptr(best_iter), r.stream()), 'spsp_fit_select')
+    translation = convert_weak_perspective_to_camera_translation_torch(cam, config.FOCAL_LENGTH, config.proxy_rep_input_wh)
+    return SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam,
+                           best_epoch=best_iter + 1, val_l2e_history=l2e_val, val_silhouette_metric_history=sil)
+
+
+def single_view_optimization_test(smpl, renderer, body_pose, global_orient, betas, pred_cam_wp, joints2D, silhouette, interation=50,
+                                  lr=None, joints2D_weight=1.0, silhouette_weight=1e6, return_history=False):
+    """Fit body of `single_view_optimization_test` (`PR/player_recon.py:1429-1557`) for a batch of players: the silhouette is IN
+    the loss (`init_loss_and_metric(True, True)`, weights 1.0 / 1e6, `:851`) next to the joints2D term, both log-variances of
+    the criterion are optimiser parameters (`:1453`), 50 epochs of Adam (lr 1e-3), the last iterate is left behind; the
+    gradient of the rendered silhouette comes from the restated neural_renderer backward pass (csrc/silhouette_grad.hip,
+    parity unpinned).  `renderer`: a `renderer.SilhouetteRenderer`; `silhouette` [B,512,512] (or one [512,512]) 0/1.
+    Returns body_pose, global_orient, betas, translation, cam_wp, log_vars [B,2]; with return_history also loss / joints2D_l2es /
+    silhouette-metric histories [B,iters] and param_history [B,iters,231] ([cam | R | betas | log_vars] each epoch evaluated)."""
+    import math
+    B = betas.shape[0]
+    full = torch.cat([rt.dev_f32(global_orient).reshape(B, 1, 3, 3), rt.dev_f32(body_pose).reshape(B, 23, 3, 3)], dim=1).contiguous()
+    r = rt.get(full.device)
+    b = rt.dev_f32(betas, r.device).clone()
+    cam = rt.dev_f32(pred_cam_wp, r.device).clone()
+    smpl.to(r.device)
+    renderer.to(r.device)
+    if B > smpl.max_batch or B > renderer.max_batch:
+        raise ValueError(f'single_view_optimization_test: batch {B} exceeds max_batch of the SMPL / renderer handle')
+    cfg = _abi.FitSilhouetteConfig()
+    r.lib.spsp_fit_silhouette_config_default(C.byref(cfg))
+    cfg.iters = int(interation)
+    if lr is not None:
+        cfg.lr = float(lr)
+    cfg.joints2d_weight, cfg.silhouette_weight = float(joints2D_weight), float(silhouette_weight)
+    lv = torch.tensor([-math.log(joints2D_weight + 1e-6), -math.log(silhouette_weight + 1e-6)], dtype=torch.float32,
+                      device=r.device).repeat(B, 1).contiguous()           # multi_task_loss.py:37-46
+    j2d = rt.dev_f32(torch.as_tensor(joints2D)[..., :2], r.device).reshape(B, 17, 2).contiguous()
+    wh = config.proxy_rep_input_wh
+    tgt = torch.as_tensor(silhouette).to(device=r.device, dtype=torch.uint8).contiguous()
+    shared = 1 if tuple(tgt.shape) == (wh, wh) else 0
+    if not shared and tuple(tgt.shape) != (B, wh, wh):
+        raise ValueError(f'single_view_optimization_test: silhouette must be [{wh},{wh}] or [B,{wh},{wh}], got {tuple(tgt.shape)}')
+    hist = [None] * 4
+    if return_history:
+        hist = [torch.empty((B, cfg.iters), dtype=torch.float32, device=r.device) for _ in range(3)]
+        hist.append(torch.empty((B, cfg.iters, _abi.RECORD_FLOATS + 2), dtype=torch.float32, device=r.device))
+    r.check(r.lib.spsp_fit_silhouette(r.ctx, smpl.handle, renderer.handle, C.byref(cfg), rt.ptr(full), rt.ptr(b), rt.ptr(cam), rt.ptr(lv),
+                                      rt.ptr(j2d), rt.ptr(tgt), shared, B, rt.ptr(hist[0]), rt.ptr(hist[1]), rt.ptr(hist[2]), rt.ptr(hist[3]),
+                                      r.stream()), 'spsp_fit_silhouette')
+    translation = convert_weak_perspective_to_camera_translation_torch(cam, config.FOCAL_LENGTH, wh)
+    out = SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam, log_vars=lv)
+    if return_history:
+        out.loss_history, out.l2e_history, out.silhouette_metric_history, out.param_history = hist
+    return out
+
+
+def multi_view_orders(V, interation, rounds, seed):
+    """The view orders of a `multi_view_optimization` run as the reference draws them: `indexes = list(range(V));
+    random.shuffle(indexes)` before EVERY pass -- train, then validation -- of every epoch of both blocks of every round
+    (`PR/player_recon.py:1746-1748, 1874-1876`), from Python's `random` seeded with `seed`.  Returns the TRAIN orders
+    [rounds * 2 * interation, V] int32 (the validation pass only sums its metrics: its order does not matter)."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    for _ in range(rounds * 2 * interation):
+        idx = list(range(V))
+        rng.shuffle(idx)
+        out.append(idx)
+        val = list(range(V))
+        rng.shuffle(val)                       # the draw the validation pass consumes
+    return torch.tensor(out, dtype=torch.int32)
+
+
 def multi_view_optimization(smpl, body_pose, global_orient, betas, translation, joints2D, interation=None, lr=None,
-                            rounds=3, optimise_body_pose=False, return_history=False):
+                            rounds=3, optimise_body_pose=False, return_history=False, view_order=None,
+                            select_mode=_abi.FIT_SELECT_BEST_L2E, silhouettes=None, renderer=None):
     """Optimisation body of `multi_view_optimization` (`PR/player_recon.py:1691-1979`) for a batch of players seen in
     V <= 4 views each.  Inputs are the per-view single-view results the reference loads from its npz records
     (`:1673-1689`; `records.load_record`): body_pose [B,V,23,3,3], global_orient [B,V,1,3,3], betas [B,V,10],
@@ -135,9 +247,15 @@ def multi_view_optimization(smpl, body_pose, global_orient, betas, translation, 
 
     As in the reference the shared body pose and betas start from the MEAN over the views (`:1691-1694`), every view
     keeps its own camera (recovered from its translation, `:1689`) and orientation, and `rounds` x {camera block, pose
-    block} of `interation` epochs run with the best mean joints2D_l2es iterate kept (csrc/fit_mv_core.hpp).
+    block} of `interation` epochs run with the best iterate kept (csrc/fit_mv_core.hpp).
     optimise_body_pose=False reproduces the reference, whose pose block only ever moves betas (the posed tensor is
     concatenated before requires_grad is set, `:1724-1731`); True optimises body_pose idx {0-5, 8-20} as intended.
+    view_order: [rounds * 2 * interation, V] -- the view each train step of each epoch visits (`multi_view_orders` draws
+    them as the reference's `random.shuffle` does); None = 0 .. V-1.
+    select_mode: FIT_SELECT_BEST_L2E -- the record is the epoch with the lowest mean joints2D_l2es, everything in ONE launch;
+    FIT_SELECT_REFERENCE -- the reference's rule (`:1820, :1937`: joints2D_l2es AND the mean rendered-silhouette metric both <=
+    their values at the previous record; needs silhouettes= [B,V,512,512] and renderer=): one launch per block, every epoch's
+    V meshes rendered, the record and the block's best epoch decided on both metrics.
 
     Returns what the reference saves (`:1976-1979`): body_pose [B,23,3,3], betas [B,10] (-> data.npz) and per view
     translation [B,V,3], global_orient [B,V,1,3,3] (-> <view>.npz), plus cam_wp [B,V,3]."""
@@ -164,17 +282,81 @@ def multi_view_optimization(smpl, body_pose, global_orient, betas, translation, 
     if lr is not None:
         cfg.lr = float(lr)
     cfg.optimise_body_pose = 1 if optimise_body_pose else 0
-    hist = torch.empty((B, cfg.rounds * 2 * cfg.iters), dtype=torch.float32, device=r.device) if return_history else None
+    order = None
+    if view_order is not None:
+        order = torch.as_tensor(view_order).to(device=r.device, dtype=torch.int32).contiguous()
+        if tuple(order.shape) != (cfg.rounds * 2 * cfg.iters, V) or not bool((order.sort(dim=1).values.cpu() == torch.arange(V)).all()):
+            raise ValueError(f'multi_view_optimization: view_order must hold {cfg.rounds * 2 * cfg.iters} permutations of 0..{V - 1}')
     smpl.to(r.device)
-    r.check(r.lib.spsp_fit_multiview(r.ctx, smpl.handle, C.byref(cfg), B, V, rt.ptr(body), rt.ptr(bmean), rt.ptr(cam),
-                                     rt.ptr(go), rt.ptr(j2d), rt.ptr(hist), r.stream()), 'spsp_fit_multiview')
+    extra = {}
+    if select_mode == FIT_SELECT_REFERENCE:
+        if silhouettes is None or renderer is None:
+            raise ValueError('multi_view_optimization: select_mode "reference" needs silhouettes= [B,V,512,512] and renderer=')
+        extra = _multi_view_reference_rule(r, smpl, renderer, cfg, B, V, body, bmean, cam, go, j2d, order, silhouettes)
+        hist = extra.pop('val_l2e')
+    else:
+        hist = torch.empty((B, cfg.rounds * 2 * cfg.iters), dtype=torch.float32, device=r.device) if return_history else None
+        r.check(r.lib.spsp_fit_multiview_ordered(r.ctx, smpl.handle, C.byref(cfg), B, V, rt.ptr(body), rt.ptr(bmean), rt.ptr(cam),
+                                                 rt.ptr(go), rt.ptr(j2d), rt.ptr(order), rt.ptr(hist), r.stream()), 'spsp_fit_multiview')
     trans = convert_weak_perspective_to_camera_translation_torch(cam.reshape(B * V, 3), config.FOCAL_LENGTH,
                                                                  config.proxy_rep_input_wh).reshape(B, V, 3)
     out = SimpleNamespace(body_pose=body.reshape(B, 23, 3, 3), betas=bmean, translation=trans,
-                          global_orient=go.reshape(B, V, 1, 3, 3), cam_wp=cam)
-    if return_history:
+                          global_orient=go.reshape(B, V, 1, 3, 3), cam_wp=cam, **extra)
+    if return_history or select_mode == FIT_SELECT_REFERENCE:
         out.val_l2e_history = hist.reshape(B, cfg.rounds, 2, cfg.iters)
     return out
+
+
+def _multi_view_reference_rule(r, smpl, renderer, cfg, B, V, body, betas, cam, go, j2d, order, silhouettes):
+    """The multi-view fit under the reference's record rule over BOTH tracked metrics (in place on body / betas / cam / go =
+    the record).  One `spsp_fit_multiview_block` launch per block (the optimisation inside a block does not depend on the
+    record), every epoch's V meshes rendered for the silhouette metric, then the sequential rule over the block's epochs with the
+    record's metrics carried along; the next block starts from the block's best epoch (`:1843-1845, :1954-1957`) -- from the
+    block's start if none of its epochs made the record."""
+    wh, it = config.proxy_rep_input_wh, cfg.iters
+    tgt = torch.as_tensor(silhouettes).to(device=r.device, dtype=torch.uint8).reshape(B, V, wh, wh).contiguous()
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=r.device)
+    st_body, st_betas, st_cam, st_go = body.clone(), betas.clone(), cam.clone(), go.clone()       # current state of the loop
+    best_l2e = torch.full((B,), float('inf'))
+    best_sil = torch.full((B,), float('inf'))
+    l2e_all, sil_all = [], []
+    for rd in range(cfg.rounds):
+        for block in (0, 1):
+            w_body, w_betas, w_cam, w_go = st_body.clone(), st_betas.clone(), st_cam.clone(), st_go.clone()
+            val, sv, ss = f32(B, it), f32(B, it, V, 12), f32(B, it, 217)
+            ordb = order[(rd * 2 + block) * it:(rd * 2 + block + 1) * it].contiguous() if order is not None else None
+            r.check(r.lib.spsp_fit_multiview_block(r.ctx, smpl.handle, C.byref(cfg), block, B, V, rt.ptr(w_body), rt.ptr(w_betas), rt.ptr(w_cam),
+                                                   rt.ptr(w_go), rt.ptr(j2d), rt.ptr(ordb), rt.ptr(val), rt.ptr(sv), rt.ptr(ss), r.stream()),
+                    'spsp_fit_multiview_block')
+            sil = torch.zeros((B, it), dtype=torch.float32, device=r.device)
+            for ep in range(it):                                  # every epoch: the V meshes its validation pass saw
+                for v in range(V):
+                    full = torch.cat([sv[:, ep, v, 3:].reshape(B, 1, 3, 3), ss[:, ep, :207].reshape(B, 23, 3, 3)], dim=1).contiguous()
+                    verts = smpl(full_pose=full, betas=ss[:, ep, 207:].contiguous(), return_joints=False).vertices
+                    t_v = convert_weak_perspective_to_camera_translation_torch(sv[:, ep, v, :3].contiguous(), config.FOCAL_LENGTH, wh)
+                    sil[:, ep] += renderer(verts, t_v, target=tgt[:, v].contiguous(), return_image=False).metric
+            sil /= V
+            vl, sl = val.cpu(), sil.cpu()
+            l2e_all.append(val)
+            sil_all.append(sil)
+            blk_best = torch.full((B,), -1, dtype=torch.long)
+            for b in range(B):                                    # determine_save_model_weights_this_epoch, epoch by epoch
+                for ep in range(it):
+                    if not (vl[b, ep] > best_l2e[b]) and not (sl[b, ep] > best_sil[b]):
+                        best_l2e[b], best_sil[b], blk_best[b] = vl[b, ep], sl[b, ep], ep
+            for b in range(B):
+                e = int(blk_best[b])
+                if e < 0:
+                    continue                                      # no record in this block: its parameters return to the block's start
+                # the record = the whole state of that epoch; the block's parameter group continues from there
+                body[b], betas[b] = ss[b, e, :207], ss[b, e, 207:]
+                cam[b], go[b] = sv[b, e, :, :3], sv[b, e, :, 3:]
+                if block == 0:
+                    st_cam[b], st_go[b] = sv[b, e, :, :3], sv[b, e, :, 3:]
+                else:
+                    st_body[b], st_betas[b] = ss[b, e, :207], ss[b, e, 207:]
+    return dict(val_l2e=torch.cat(l2e_all, dim=1), val_silhouette_metric_history=torch.cat(sil_all, dim=1).reshape(B, cfg.rounds, 2, it),
+                record_l2e=best_l2e, record_silhouette_metric=best_sil)
 
 
 def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape', iters=50, lr=None,

@@ -326,6 +326,155 @@ def test_reference_best_iterate_rule_with_the_rendered_silhouette_metric(smpl_gp
         single_view_optimization(smpl_gpu, R0[:, 1:], R0[:, :1], b0, cam0, tgt, select_mode=FIT_SELECT_REFERENCE)
 
 
+def test_smpl_vertices_vjp_against_autograd(smpl_gpu, oracle_smpl, dev):
+    """csrc/smpl_vjp.hip -- dL/dvertices -> (dL/dR, dL/dbetas), what `loss.backward()` does to the mesh when the silhouette is
+    in the loss -- against torch.autograd through the oracle SMPL on random non-orthonormal matrices; B = 9 (ragged against the
+    skin kernel's 8-player workgroups).  Tolerance: 2e-5 of the largest gradient entry (fp32 sums over 6890 vertices)."""
+    B = 9
+    R, betas, _ = S.pose_params(B, seed=71, body_deg=35, global_deg=60)
+    R = R + 0.05 * S.hash_normal(R.size, 'vjpR').reshape(R.shape).astype(np.float32)
+    G = S.hash_normal(B * 6890 * 3, 'vjpG').reshape(B, 6890, 3).astype(np.float32)
+    Rt, bt = torch.from_numpy(R).requires_grad_(True), torch.from_numpy(betas).requires_grad_(True)
+    v = oracle_smpl(body_pose=Rt[:, 1:], global_orient=Rt[:, :1], betas=bt).vertices
+    (v * torch.from_numpy(G)).sum().backward()
+    gR, gb = smpl_gpu.vertices_vjp(torch.from_numpy(R).to(dev), torch.from_numpy(betas).to(dev), torch.from_numpy(G).to(dev))
+    sR, sb = Rt.grad.abs().max().item(), bt.grad.abs().max().item()
+    assert (gR.cpu() - Rt.grad).abs().max().item() < 2e-5 * sR, ((gR.cpu() - Rt.grad).abs().max().item(), sR)
+    assert (gb.cpu() - bt.grad).abs().max().item() < 2e-5 * sb, ((gb.cpu() - bt.grad).abs().max().item(), sb)
+
+
+def _shifted_silhouette_case(smpl_model_np, B, seed):
+    """B posed meshes and, as the detected silhouette of each, the render of the same mesh slightly moved and re-posed."""
+    from oracle import smpl as OS, silhouette as OSil, geometry as G
+    R, betas, cam = S.pose_params(B, seed=seed, body_deg=25, global_deg=40)
+    v, j = OS.smpl_forward_np(smpl_model_np, R, betas)
+    Rn, bn, _ = S.pose_params(B, seed=seed + 1, body_deg=6, global_deg=8)
+    R2 = (Rn.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    v2, j2 = OS.smpl_forward_np(smpl_model_np, R2, (betas + bn / 2).astype(np.float32))
+    cam2 = (cam * np.array([1.06, 1, 1]) + np.array([0, 0.02, -0.015])).astype(np.float32)
+    trans, trans2 = G.wp_to_translation(torch.from_numpy(cam)).numpy(), G.wp_to_translation(torch.from_numpy(cam2)).numpy()
+    target = np.stack([(OSil.render_silhouette(v2[b].astype(np.float32), smpl_model_np['faces'], trans2[b]) > 0.5) for b in range(B)]).astype(np.uint8)
+    return R, betas, cam, v.astype(np.float32), trans.astype(np.float32), target, j2, cam2
+
+
+def test_silhouette_loss_and_gradient_against_restated_neural_renderer_backward(smpl_gpu, smpl_model_np, dev):
+    """csrc/silhouette_grad.hip vs oracle/silhouette_grad.py (neural_renderer's rasteriser WITH its approximate backward pass,
+    restated; parity unpinned): the image of the ownership raster equals the coverage raster's, the loss sum, and
+    dL/dvertices / dL/dtranslation of L = -S w against torch.autograd through the restated renderer.  The gradient is a sum
+    of +-diff / dist terms of up to 1e6 / 1e-4 each: tolerance 1e-4 of its largest entry."""
+    from soccerplayershapepose_amd.renderer import SilhouetteRenderer
+    from oracle import silhouette_grad as OG
+    B = 2
+    R, betas, cam, v, trans, target, _, _ = _shifted_silhouette_case(smpl_model_np, B, seed=81)
+    rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=4).to(dev)
+    w = np.array([1e6, 3.0], np.float32)
+    out = rend.loss_grad(torch.from_numpy(v).to(dev), trans, target, weight=w, return_image=True)
+    plain = rend(torch.from_numpy(v).to(dev), trans, target=target)
+    assert torch.equal(out.silhouettes, plain.silhouettes)
+    np.testing.assert_allclose(-out.sil_sum.cpu().numpy(), plain.metric.cpu().numpy(), rtol=1e-5)
+    for b in range(B):
+        vt = torch.from_numpy(v[b]).requires_grad_(True)
+        tt = torch.from_numpy(trans[b]).requires_grad_(True)
+        img = OG.render_silhouette_torch(vt, smpl_model_np['faces'], tt)
+        tg = torch.from_numpy(target[b].astype(np.float32))
+        S_ = torch.sum(img * torch.log(tg + 1e-6) + (1 - img) * torch.log(1 - tg + 1e-6))
+        (-S_ * float(w[b])).backward()
+        assert np.array_equal(img.detach().numpy(), out.silhouettes[b].cpu().numpy())
+        assert abs(out.sil_sum[b].item() - S_.item()) <= 2e-5 * abs(S_.item())
+        gv, gt = out.grad_vertices[b].cpu(), out.grad_translation[b].cpu()
+        sc = vt.grad.abs().max().item()
+        assert sc > 0
+        dv = (gv - vt.grad).abs().amax(dim=1)
+        rel = (gv - vt.grad).norm().item() / vt.grad.norm().item()
+        print(f'mesh {b}: dL/dvertices relative L2 deviation {rel:.2e}, max {dv.max().item():.3e} of {sc:.3e}, vertices beyond 1e-4 of the scale: {int((dv > 1e-4 * sc).sum())}')
+        bad = dv.max().item()
+        assert bad < 1e-4 * sc, f'mesh {b}: dL/dvertices deviates by {bad} (largest entry {sc})'
+        assert (gt - tt.grad).abs().max().item() < 1e-4 * tt.grad.abs().max().item(), (gt, tt.grad)
+    with pytest.raises(ValueError):
+        rend.loss_grad(torch.from_numpy(v).to(dev), trans, target[:, :100], weight=w)
+
+
+def test_fit_with_the_silhouette_in_the_loss_against_the_autograd_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """`single_view_optimization_test` (`PR/player_recon.py:1429-1557`): joints2D + silhouette loss, the criterion's two
+    log-variances in the optimiser, the silhouette term reaching the camera from the second epoch on.  GPU: one chain of
+    launches per epoch (csrc/fit_sil.hip); oracle: torch.autograd through the oracle SMPL and the restated neural_renderer,
+    torch.optim.Adam.  Parameters evaluated at epochs 1, 2 and 10 and after the 10th step; histories of the loss terms.
+    Tolerances: 5e-5 at epochs 1-2 (one Adam step moves every parameter by lr = 1e-3 whatever its gradient: a sign must not
+    flip), 3e-4 after ten."""
+    from soccerplayershapepose_amd.player_recon import single_view_optimization_test
+    from soccerplayershapepose_amd.renderer import SilhouetteRenderer
+    from oracle import silhouette_grad as OG
+    iters = 10
+    R, betas, cam, v, trans, target, j2, cam2 = _shifted_silhouette_case(smpl_model_np, 1, seed=91)
+    tgt_j = S.fit_targets_from_joints(j2, cam2, seed=92)
+    rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=4).to(dev)
+    out = single_view_optimization_test(smpl_gpu, rend, R[:, 1:], R[:, :1], betas, cam, tgt_j, target, interation=iters, return_history=True)
+    rec = {}
+    ref = OG.fit_pose_shape_silhouette(oracle_smpl, smpl_model_np['faces'], torch.from_numpy(R[:, 1:]), torch.from_numpy(R[:, :1]),
+                                       torch.from_numpy(betas), tgt_j[0], target[0], torch.from_numpy(cam), iters=iters, record=rec)
+    ph = out.param_history[0].cpu().numpy()                      # [iters, 231]: the parameters each epoch EVALUATED
+    np.testing.assert_allclose(out.l2e_history[0].cpu().numpy(), rec['l2e'], rtol=2e-3)
+    np.testing.assert_allclose(out.silhouette_metric_history[0].cpu().numpy(), rec['sil_metric'], rtol=2e-3)
+    np.testing.assert_allclose(out.loss_history[0].cpu().numpy(), rec['loss'], rtol=2e-3)
+    for ep, tol in ((1, 5e-5), (2, 5e-5), (9, 3e-4)):            # ph[ep] = the result of step ep (0-based: after ep steps)
+        want = np.concatenate([rec['cam'][ep - 1].reshape(-1), rec['G'][ep - 1].reshape(-1), rec['body'][ep - 1].reshape(-1),
+                               rec['betas'][ep - 1].reshape(-1), rec['lv'][ep - 1].reshape(-1)])
+        dev_ = np.abs(ph[ep] - want)
+        print(f'silhouette fit, after step {ep}: max parameter deviation {dev_.max():.2e} (parameter {int(dev_.argmax())}), {int((dev_ > tol).sum())} beyond {tol}')
+        assert dev_.max() < tol, f'after step {ep}: {dev_.max()} at parameter {int(dev_.argmax())}'
+    body, Gm, be, ca, lvj, lvs = ref['last']
+    assert (out.body_pose[0].cpu() - body[0]).abs().max().item() < 3e-4 and (out.cam_wp[0].cpu() - ca[0]).abs().max().item() < 3e-4
+    assert (out.betas[0].cpu() - be[0]).abs().max().item() < 3e-4 and (out.global_orient[0].cpu() - Gm[0]).abs().max().item() < 3e-4
+    np.testing.assert_allclose(out.log_vars[0].cpu().numpy(), [lvj, lvs], atol=3e-4)
+    assert rec['sil_metric'][-1] < rec['sil_metric'][0]           # and the silhouette term does pull the mesh into the target
+
+
+def test_broad_view_optimization_against_the_autograd_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """`broad_view_optimization` (`PR/player_recon.py:2128-2229`): camera + global orientation, lr 1e-2, 100
+    epochs, train pass then validation pass, the best validation epoch saved.  (i) the reference's sizes with the joints2D
+    metric alone; (ii) 12 epochs under the reference's two-metric rule, the silhouette metric of every validation iterate
+    rendered on both sides.  Tolerances: validation l2e histories 2e-3 relative, the saved parameters 2e-4 / 5e-5, the saved
+    epoch equal."""
+    from soccerplayershapepose_amd.player_recon import broad_view_optimization, FIT_SELECT_REFERENCE
+    from soccerplayershapepose_amd.renderer import SilhouetteRenderer
+    from oracle import fit as OF, smpl as OS, silhouette as OSil, geometry as G
+    B = 2
+    R, betas, cam = S.pose_params(B, seed=101, body_deg=20, global_deg=30)
+    _, jt = OS.smpl_forward_np(smpl_model_np, R, betas)
+    tgt = S.fit_targets_from_joints(jt, cam, seed=102)
+    Rn, _, _ = S.pose_params(B, seed=103, body_deg=0, global_deg=12)
+    G0 = (Rn[:, :1].astype(np.float64) @ R[:, :1].astype(np.float64)).astype(np.float32)     # what the regressor gives on the broad view
+    cam0 = (cam * np.array([1.1, 1, 1]) + np.array([0, 0.03, -0.02])).astype(np.float32)
+    out = broad_view_optimization(smpl_gpu, R[:, 1:], G0, betas, cam0, tgt)
+    assert out.val_l2e_history.shape == (B, 100)
+    for b in range(B):
+        ref = OF.fit_broad_view(oracle_smpl, torch.from_numpy(R[b:b + 1, 1:]), torch.from_numpy(G0[b:b + 1]), torch.from_numpy(betas[b:b + 1]),
+                                tgt[b], torch.from_numpy(cam0[b:b + 1]))
+        np.testing.assert_allclose(out.val_l2e_history[b].cpu().numpy(), ref['val_l2e'], rtol=2e-3)
+        assert int(out.best_epoch[b]) == ref['best_epoch']
+        np.testing.assert_allclose(out.global_orient[b].cpu().numpy(), ref['best'][0][0].numpy(), atol=2e-4)
+        np.testing.assert_allclose(out.cam_wp[b].cpu().numpy(), ref['best'][1][0].numpy(), atol=2e-4)
+    assert torch.equal(out.body_pose.cpu(), torch.from_numpy(R[:, 1:])) and torch.equal(out.betas.cpu(), torch.from_numpy(betas))
+    # (ii) the two-metric rule, a large learning rate so that it has something to decide
+    vt, _ = OS.smpl_forward_np(smpl_model_np, R, betas)
+    trans_t = G.wp_to_translation(torch.from_numpy(cam)).numpy()
+    sil_t = np.stack([(OSil.render_silhouette(vt[b].astype(np.float32), smpl_model_np['faces'], trans_t[b]) > 0.5) for b in range(B)]).astype(np.uint8)
+    rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=4).to(dev)
+    out = broad_view_optimization(smpl_gpu, R[:, 1:], G0, betas, cam0, tgt, interation=12, lr=0.05, select_mode=FIT_SELECT_REFERENCE,
+                                  silhouette=sil_t, renderer=rend)
+    for b in range(B):
+        metric = lambda verts, c, b=b: OSil.silhouette_metric(OSil.render_silhouette(verts.astype(np.float32), smpl_model_np['faces'],
+                                                               G.wp_to_translation(torch.from_numpy(c[None])).numpy()[0]), sil_t[b])
+        ref = OF.fit_broad_view(oracle_smpl, torch.from_numpy(R[b:b + 1, 1:]), torch.from_numpy(G0[b:b + 1]), torch.from_numpy(betas[b:b + 1]),
+                                tgt[b], torch.from_numpy(cam0[b:b + 1]), lr=0.05, iters=12, silhouette_metric=metric)
+        np.testing.assert_allclose(out.val_l2e_history[b].cpu().numpy(), ref['val_l2e'], rtol=2e-3)
+        np.testing.assert_allclose(out.val_silhouette_metric_history[b].cpu().numpy(), ref['val_sil'], rtol=5e-3)
+        assert int(out.best_epoch[b]) == ref['best_epoch'], (int(out.best_epoch[b]), ref['best_epoch'], ref['val_l2e'], ref['val_sil'])
+        np.testing.assert_allclose(out.cam_wp[b].cpu().numpy(), ref['best'][1][0].numpy(), atol=5e-4)
+    with pytest.raises(ValueError):
+        broad_view_optimization(smpl_gpu, R[:, 1:], G0, betas, cam0, tgt, select_mode=FIT_SELECT_REFERENCE)
+
+
 # ---------------------------------------------------------------- multi-view fit (8f-3) and the on-disk records (a14)
 @pytest.mark.parametrize('optimise_body_pose', [False, True])
 def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev, optimise_body_pose, tmp_path):
@@ -402,6 +551,55 @@ def test_multi_view_fit_at_the_reference_operating_point_50_epochs_3_rounds(smpl
         print(f'multi-view 50 x 3, V = {V}, optimise_body_pose = {obp}: {devs}')
         assert max(devs.values()) < (1e-2 if obp else 1e-4), devs
         assert abs(float(hist.min()) - float(ref['best_val'])) < 2e-2 * float(ref['best_val'])      # the record itself: within 2 %
+
+
+def test_multi_view_fit_under_the_reference_record_rule_and_shuffled_view_orders(smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """`multi_view_optimization` as the reference decides its record (`PR/player_recon.py:1820, 1937`: mean joints2D_l2es AND the
+    mean rendered-silhouette metric over the views) and visits the views (`random.shuffle` before every pass, `:1748, :1876`):
+    per-block launches + renders on the GPU against the autograd oracle given the same drawn orders and the restated renderer.
+    A large learning rate makes both metrics non-monotonic, so the rule and the block restarts have something to decide."""
+    from soccerplayershapepose_amd.player_recon import multi_view_optimization, multi_view_orders, FIT_SELECT_REFERENCE
+    from soccerplayershapepose_amd.renderer import SilhouetteRenderer
+    from oracle import fit_multiview as OMV, silhouette as OSil, geometry as G, smpl as OS
+    from test_fit_multiview_emulation import multiview_case
+    V, iters, rounds, lr = 3, 4, 2, 0.02
+    views = multiview_case(smpl_model_np, V, seed=57)
+    orders = multi_view_orders(V, iters, rounds, seed=5)
+    assert orders.shape == (rounds * 2 * iters, V) and len({tuple(o.tolist()) for o in orders}) > 1
+    # detected silhouettes: every view's single-view result rendered, shifted a little
+    sil = []
+    for body, go, betas, trans, _ in views:
+        v, _ = OS.smpl_forward_np(smpl_model_np, np.concatenate([go, body], axis=1).astype(np.float32), betas.astype(np.float32))
+        sil.append(OSil.render_silhouette(v[0].astype(np.float32), smpl_model_np['faces'], (trans[0] + np.array([0.02, -0.02, 0.3])).astype(np.float32)) > 0.5)
+    sil = np.stack(sil).astype(np.uint8)
+    st = lambda k: np.stack([v[k][0] for v in views])[None]
+    rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=4).to(dev)
+    out = multi_view_optimization(smpl_gpu, st(0), st(1), st(2), st(3), np.stack([v[4] for v in views])[None], interation=iters, rounds=rounds,
+                                  lr=lr, optimise_body_pose=True, view_order=orders, select_mode=FIT_SELECT_REFERENCE, silhouettes=sil[None],
+                                  renderer=rend)
+    metric = lambda view, verts, c: OSil.silhouette_metric(OSil.render_silhouette(verts.astype(np.float32), smpl_model_np['faces'],
+                                                            G.wp_to_translation(torch.from_numpy(c[None])).numpy()[0]), sil[view])
+    t = lambda k: torch.from_numpy(np.stack([v[k] for v in views]))
+    ref = OMV.fit_multi_view(oracle_smpl, t(0), t(1), t(2), t(3), [v[4] for v in views], lr=lr, iters=iters, rounds=rounds, stale_pose_cat=False,
+                             view_orders=orders.numpy(), silhouette_metric=metric)
+    np.testing.assert_allclose(out.val_l2e_history[0].cpu().numpy().reshape(-1), ref['val_history'], rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(out.val_silhouette_metric_history[0].cpu().numpy().reshape(-1), ref['sil_history'], rtol=5e-3)
+    assert abs(float(out.record_l2e[0]) - ref['best_val']) < 2e-3 * ref['best_val'] + 2e-2
+    assert abs(float(out.record_silhouette_metric[0]) - ref['best_sil']) < 5e-3 * ref['best_sil']
+    np.testing.assert_allclose(out.cam_wp[0].cpu().numpy(), ref['cam_wp'][:, 0], atol=2e-3)
+    np.testing.assert_allclose(out.betas[0].cpu().numpy(), ref['betas'][0], atol=2e-3)
+    np.testing.assert_allclose(out.body_pose[0].cpu().numpy(), ref['body_pose'][0], atol=2e-3)
+    np.testing.assert_allclose(out.global_orient[0, :, 0].cpu().numpy(), ref['global_orient'][:, 0, 0], atol=2e-3)
+    # the ordered single-launch form (joints2D_l2es record) against the oracle with the same orders
+    out2 = multi_view_optimization(smpl_gpu, st(0), st(1), st(2), st(3), np.stack([v[4] for v in views])[None], interation=iters, rounds=rounds,
+                                   lr=lr, optimise_body_pose=True, view_order=orders, return_history=True)
+    ref2 = OMV.fit_multi_view(oracle_smpl, t(0), t(1), t(2), t(3), [v[4] for v in views], lr=lr, iters=iters, rounds=rounds, stale_pose_cat=False,
+                              view_orders=orders.numpy())
+    np.testing.assert_allclose(out2.val_l2e_history[0].cpu().numpy().reshape(-1), ref2['val_history'], rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(out2.cam_wp[0].cpu().numpy(), ref2['cam_wp'][:, 0], atol=2e-3)
+    with pytest.raises(ValueError):
+        multi_view_optimization(smpl_gpu, st(0), st(1), st(2), st(3), np.stack([v[4] for v in views])[None], interation=iters, rounds=rounds,
+                                view_order=orders[:3])
 
 
 def test_single_view_fit_warm_started_from_its_own_record_continues_the_trajectory(smpl_gpu, smpl_model_np, dev, tmp_path):

@@ -1,0 +1,66 @@
+"""A/B of regressor plans in the PIPELINED throughput mode (4 slots, HIP graphs) inside one process: players/s of the whole
+path (regressor -> fit -> SMPL) for each plan, measured in interleaved rounds so that box / clock differences cancel.
+usage: python tools/ab_pipeline.py [steps] [rounds]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+import torch  # noqa: E402
+
+from soccerplayershapepose_amd import _abi, synthetic as S  # noqa: E402
+from soccerplayershapepose_amd import runtime as rt  # noqa: E402
+from soccerplayershapepose_amd.models.regressor import SingleInputRegressor  # noqa: E402
+from soccerplayershapepose_amd.models.smpl_official import SMPL  # noqa: E402
+from soccerplayershapepose_amd.player_recon import PlayerPipeline  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+B = 32
+dev = torch.device('cuda', 0)
+r = rt.get(dev)
+sd, model = S.regressor_state_dict(seed=0), S.smpl_model(seed=0)
+
+
+def patch(L, tile, ring, db):
+    return (_abi.DEBUG_PLAN_PATCH, L * 10000 + tile * 10 + ring * 2 + db)
+
+
+PLANS = {
+    'round2 (ring s2, layer4 64ch)': [(_abi.DEBUG_PLAN_S2, 0), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
+    's2 + layer4 64ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
+    's2 + layer4 32ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)],
+    's2 + 64ch + small-LDS patch kernels (128 px, ring 2, one patch: 2 per CU)':
+        [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 2, 0), patch(2, 128, 2, 0), patch(3, 128, 2, 0)],
+    's2 + 64ch + layer2 as 128 px, ring 3, one patch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 3, 0)],
+}
+streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+x, _ = S.proxy_crops(B, seed=1234)
+tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(3)) * 300 + 100).to(dev)
+pipes = {}
+for name, hooks in PLANS.items():
+    def mk_r(hooks=hooks):
+        reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(sd).to(dev)
+        for what, val in hooks:
+            r.check(r.lib.spsp_regressor_debug(reg.handle, what, val), 'spsp_regressor_debug')
+        return reg
+    pipe = PlayerPipeline(mk_r, lambda: SMPL(model, max_batch=B), dev, depth=4, use_graphs=True, streams=streams)
+    natives = [pipe.slots[0].regressor.pack(torch.from_numpy(x).to(dev)) for _ in range(4)]
+    for i in range(8):
+        pipe.submit(natives[i % 4], tgt, fit='pose_shape', iters=50)
+    torch.cuda.synchronize()
+    pipes[name] = (pipe, natives)
+res = {k: [] for k in PLANS}
+for rd in range(rounds):
+    for name, (pipe, natives) in pipes.items():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = pipe.submit(natives[i % 4], tgt, fit='pose_shape', iters=50)
+        torch.cuda.synchronize()
+        res[name].append(B * steps / (time.perf_counter() - t0))
+        assert torch.isfinite(out.vertices).all()
+for name, v in res.items():
+    print(f'{sorted(v)[len(v) // 2]:9.0f} players/s (median of {[round(a) for a in v]})  {name}')
