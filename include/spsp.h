@@ -311,7 +311,8 @@ int  spsp_smpl_vertices_vjp(spsp_ctx* ctx, spsp_smpl* s, const float* R, const f
  * cam, betas, joints2D_log_var, silhouette_log_var}, torch.optim.Adam, `iters` epochs, the LAST iterate left in place.
  * log_vars [B,2] in/out (the caller initialises them to -ln(weight + 1e-6), multi_task_loss.py:37-46); histories [B,iters] optional:
  * loss, joints2D_l2es, the silhouette metric (-sil_sum); param_hist [B,iters,231] = [cam | R | betas | log_vars] each epoch
- * evaluated.  Every epoch is a chain of launches on `stream`; no host synchronisation. */
+ * evaluated, grad_hist [B,iters,231] the gradient of the loss there (entries of frozen parameters are not used).  Every epoch is a
+ * chain of launches on `stream`; no host synchronisation. */
 typedef struct {
     int      iters;                              /* 50 (PR/player_recon.py:1457) */
     double   lr, beta1, beta2, eps;              /* 1e-3 (S/global_var.py:71), torch.optim.Adam defaults */
@@ -322,7 +323,7 @@ typedef struct {
 void spsp_fit_silhouette_config_default(spsp_fit_silhouette_config* c);
 int  spsp_fit_silhouette(spsp_ctx* ctx, spsp_smpl* s, spsp_rasterizer* rast, const spsp_fit_silhouette_config* cfg, float* R, float* betas,
                          float* cam, float* log_vars, const float* joints2d, const uint8_t* target, int target_shared, int B,
-                         float* loss_hist, float* l2e_hist, float* sil_hist, float* param_hist, void* stream);
+                         float* loss_hist, float* l2e_hist, float* sil_hist, float* param_hist, float* grad_hist, void* stream);
 
 /* ---- multi-view joint fit: replaces the optimisation body of multi_view_optimization (PR/player_recon.py:1691-1979):
  *      V <= 4 views of one player share body pose and betas, each view has its camera and global orientation.

@@ -168,7 +168,7 @@ _PROTOS = {
     'spsp_smpl_vertices_vjp': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     'spsp_fit_silhouette_config_default': (None, [C.POINTER(FitSilhouetteConfig)]),
     'spsp_fit_silhouette': (C.c_int, [_vp, _vp, _vp, C.POINTER(FitSilhouetteConfig), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp,
-                                      _vp, _vp, _vp]),
+                                      _vp, _vp, _vp, _vp]),
     'spsp_fit_select': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'spsp_fit_multiview_config_default': (None, [C.POINTER(FitMultiviewConfig)]),
     'spsp_fit_multiview': (C.c_int, [_vp, _vp, C.POINTER(FitMultiviewConfig), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

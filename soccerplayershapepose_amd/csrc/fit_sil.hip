@@ -39,7 +39,7 @@ struct SilStep {
     const float* joints2d;
     const float* seeds; const float* gcoef; const float* misc;
     float* adam;                                                  // [B][2][232]: m, v of parameter p (229 = lv_j, 230 = lv_s)
-    float* loss_hist; float* l2e_hist; float* sil_hist; float* param_hist;
+    float* loss_hist; float* l2e_hist; float* sil_hist; float* param_hist; float* grad_hist;
     int it, iters, cam_from_silhouette;
     float focal, res;
     float w1, b2, w2, eps, step_size, bc2_sqrt;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_sil_step_kernel(FitParams
             g = S * w_s + 1.f;
         }
         if (a.param_hist) a.param_hist[((size_t)b * a.iters + a.it) * (kNumPrm + 2) + p] = cur;
+        if (a.grad_hist) a.grad_hist[((size_t)b * a.iters + a.it) * (kNumPrm + 2) + p] = g;
         const bool trainable = p >= kNumPrm || r.trainable;
         if (trainable) {
             float* mv = a.adam + (size_t)b * 2 * 232;
@@ -141,7 +142,7 @@ void spsp_fit_silhouette_config_default(spsp_fit_silhouette_config* c) {
 
 int spsp_fit_silhouette(spsp_ctx* ctx, spsp_smpl* s, spsp_rasterizer* rast, const spsp_fit_silhouette_config* cfg, float* R, float* betas,
                         float* cam, float* log_vars, const float* joints2d, const uint8_t* target, int target_shared, int B,
-                        float* loss_hist, float* l2e_hist, float* sil_hist, float* param_hist, void* stream) {
+                        float* loss_hist, float* l2e_hist, float* sil_hist, float* param_hist, float* grad_hist, void* stream) {
     using namespace spsp;
     SPSP_REQUIRE(ctx && s && rast && cfg, "spsp_fit_silhouette: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));
@@ -174,7 +175,7 @@ int spsp_fit_silhouette(spsp_ctx* ctx, spsp_smpl* s, spsp_rasterizer* rast, cons
         SilStep a;
         a.R = R; a.betas = betas; a.cam = cam; a.logvars = log_vars; a.joints2d = joints2d;
         a.seeds = s->ws_seeds; a.gcoef = s->ws_gcoef; a.misc = s->ws_misc; a.adam = s->ws_adam;
-        a.loss_hist = loss_hist; a.l2e_hist = l2e_hist; a.sil_hist = sil_hist; a.param_hist = param_hist;
+        a.loss_hist = loss_hist; a.l2e_hist = l2e_hist; a.sil_hist = sil_hist; a.param_hist = param_hist; a.grad_hist = grad_hist;
         a.it = it; a.iters = cfg->iters; a.cam_from_silhouette = it > 0;
         a.focal = cfg->focal; a.res = cfg->img_wh;
         a.w1 = (float)(1.0 - cfg->beta1); a.b2 = (float)cfg->beta2; a.w2 = (float)(1.0 - cfg->beta2); a.eps = (float)cfg->eps;

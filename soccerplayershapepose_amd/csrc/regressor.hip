@@ -98,10 +98,16 @@ __global__ void read_stage_kernel(const uint16_t* __restrict__ in, float* __rest
 // broadcast ds_read_b128 (16 lanes x 16 B contiguous: conflict-free), and the 16 k-slices of a DPP row are summed with
 // four row operations.  Lane s of a row then owns output (neuron s&7, player s>>3) for the whole kernel: W1f feat and
 // the running sum S live in its registers.
-// Hand-off between layers = the placement-independent agent-scope barrier of the guide (Guideline 16): every wave drains
-// its stores, workgroup barrier, lane 0 releases (L2 write-back), adds to a monotonic counter (zeroed by a memset node
-// before the launch), polls it relaxed with s_sleep, acquires (L1 invalidate), workgroup barrier, plain loads.  Spins
-// are bounded; a time-out leaves NaNs in the outputs instead of hanging the GPU.
+// Hand-off between layers (round 3): NO fences.  The hidden vectors that cross workgroups are stored with agent-scope (sc1,
+// write-through) stores and read with sc1 loads to registers, which bypass the reader's L1 and see other XCDs' stores -- the
+// release (L2 write-back) and acquire (L1 invalidate) of the guide's Guideline 16 barrier, ~3.4 us of the ~5 us a hand-off cost
+// in round 2, are gone.  The form is the guide's (MI355X_MICROARCH.md, "Valid forms", third row of its table): every storing
+// wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to the monotonic counter (agent-scope atomic,
+// zeroed by a memset node before the launch); the consumer's lane 0 polls it with sc1 loads (s_sleep between polls), workgroup
+// barrier between the poll and EVERY load of the handed-off bytes; each 128-byte line is written whole by one store
+// instruction of one wave -- for that the vectors live in a BLOCKED layout [neuron block g][player][8 neurons]: workgroup g
+// writes 1 KB contiguous, thread t float t -- and every load of them is a global_load_dwordx4 sc1.  Spins are bounded; a
+// time-out leaves NaNs in the outputs, raises the handle's status word and the next call returns SPSP_EHIP.
 constexpr int kIefG = 64;          // workgroups per block of 32 players
 constexpr int kIefLds = 4 * 8 * 512 * 4;   // four [8][512] fp32 weight slices
 
@@ -118,24 +124,47 @@ struct IefArgs {
 
 __device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned int target, unsigned int spin_limit) {
     __shared__ int ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its stores have left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave: its (write-through) stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-back itself (hipcc may drop the fence's own wait)
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned int spins = 0;
         int good = 1;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {      // global_load_dword sc1
             __builtin_amdgcn_s_sleep(2);
             if (++spins > spin_limit) { good = 0; break; }        // 2^22: ~ seconds -- a workgroup never became resident
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ok = good;
     }
-    __syncthreads();
+    __syncthreads();                                              // between the poll and every load of the handed-off bytes
     return ok != 0;
+}
+
+
+
+// 2 x 8 float4 of the two players' k-slices, every load sc1 (L1-bypassing, sees other XCDs' write-through stores); the wait is
+// inside the statement: hipcc considers asm outputs written when the statement ends
+__device__ __forceinline__ void ief_load_sc1(const float* x0, const float* x1, int s, bool blocked, float4 (&xa)[8], float4 (&xb)[8]) {
+    const float *pa[8], *pb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = 4 * (16 * u + s);
+        const int off = blocked ? ((k >> 3) * 32) * 8 + (k & 7) : k;        // blocked: x0 / x1 point at the player's slot of block 0
+        pa[u] = x0 + off;
+        pb[u] = x1 + off;
+    }
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %17, off sc1\n\tglobal_load_dwordx4 %2, %18, off sc1\n\t"
+        "global_load_dwordx4 %3, %19, off sc1\n\tglobal_load_dwordx4 %4, %20, off sc1\n\tglobal_load_dwordx4 %5, %21, off sc1\n\t"
+        "global_load_dwordx4 %6, %22, off sc1\n\tglobal_load_dwordx4 %7, %23, off sc1\n\tglobal_load_dwordx4 %8, %24, off sc1\n\t"
+        "global_load_dwordx4 %9, %25, off sc1\n\tglobal_load_dwordx4 %10, %26, off sc1\n\tglobal_load_dwordx4 %11, %27, off sc1\n\t"
+        "global_load_dwordx4 %12, %28, off sc1\n\tglobal_load_dwordx4 %13, %29, off sc1\n\tglobal_load_dwordx4 %14, %30, off sc1\n\t"
+        "global_load_dwordx4 %15, %31, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(xa[0]), "=&v"(xa[1]), "=&v"(xa[2]), "=&v"(xa[3]), "=&v"(xa[4]), "=&v"(xa[5]), "=&v"(xa[6]), "=&v"(xa[7]),
+          "=&v"(xb[0]), "=&v"(xb[1]), "=&v"(xb[2]), "=&v"(xb[3]), "=&v"(xb[4]), "=&v"(xb[5]), "=&v"(xb[6]), "=&v"(xb[7])
+        : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pa[4]), "v"(pa[5]), "v"(pa[6]), "v"(pa[7]),
+          "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]), "v"(pb[4]), "v"(pb[5]), "v"(pb[6]), "v"(pb[7])
+        : "memory");
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane
@@ -147,15 +176,12 @@ __device__ __forceinline__ float ief_row_sum(float v) {
     return v;
 }
 
-// One 8-neuron x 2-player product over K = 512: x rows from global memory, the weight slice from LDS.  Returns, in lane s
+// One 8-neuron x 2-player product over K = 512: x rows from global memory (blocked: a handed-off vector, sc1 loads from the
+// blocked layout; else the pooled features of the previous launch, plain rows), the weight slice from LDS.  Returns, in lane s
 // of each row, the dot product for (neuron s & 7, player s >> 3).
-__device__ __forceinline__ float ief_product(const float* wl, const float* x0, const float* x1, int s) {
+__device__ __forceinline__ float ief_product(const float* wl, const float* x0, const float* x1, int s, bool blocked) {
     float4 xa[8], xb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        xa[u] = *reinterpret_cast<const float4*>(x0 + 4 * (16 * u + s));
-        xb[u] = *reinterpret_cast<const float4*>(x1 + 4 * (16 * u + s));
-    }
+    ief_load_sc1(x0, x1, s, blocked, xa, xb);
     float mine = 0.f;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -200,27 +226,34 @@ __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
     }
     __syncthreads();
 
-    const float f1 = ief_product(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s);
-    if (live) a.h1[(size_t)b * kHid + n] = fmaxf(f1 + a.cvec[n], 0.f);
+    // hidden vectors of this block of 32 players: blocked layout, this thread's element (its player, its neuron) = float
+    // g * 256 + t of the 64 KB block; players beyond B are computed (from the last real one) and stored too, so that every
+    // 128-byte line is written whole by one store instruction
+    float* const h1b = a.h1 + (size_t)pb * 32 * kHid;
+    float* const sb = a.s + (size_t)pb * 32 * kHid;
+    const int mine = g * 256 + t;
+    const int pA = 2 * pair, pB = 2 * pair + 1;                    // the pair's slots in the block
+    const float f1 = ief_product(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s, false);
+    __hip_atomic_store(h1b + mine, fmaxf(f1 + a.cvec[n], 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
     float ssum = 0.f;
     const float b2 = a.b2[n];
     for (int it = 0; it < a.iters; ++it) {
         if (it > 0) {
-            const float v = ief_product(ief_w + 4096, a.s + (size_t)rA * kHid, a.s + (size_t)rB * kHid, s);
-            if (live) a.h1[(size_t)b * kHid + n] = fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f);
+            const float v = ief_product(ief_w + 4096, sb + pA * 8, sb + pB * 8, s, true);
+            __hip_atomic_store(h1b + mine, fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok &= ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
         }
-        const float v = ief_product(ief_w + 2 * 4096, a.h1 + (size_t)rA * kHid, a.h1 + (size_t)rB * kHid, s);
+        const float v = ief_product(ief_w + 2 * 4096, h1b + pA * 8, h1b + pB * 8, s, true);
         ssum += fmaxf(b2 + v, 0.f);
-        if (live) a.s[(size_t)b * kHid + n] = ssum;
+        __hip_atomic_store(sb + mine, ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok &= ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
     }
     // A hand-off that gave up: the outputs become NaN (nothing downstream can mistake them for a result) AND the handle's
     // host-visible status word is set, so that the next call on the handle returns SPSP_EHIP (spsp_regressor_status).
     if (!ok && t == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (8 * g < kNPar) {
-        float v = a.p0[n < kNPar ? n : 0] + ief_product(ief_w + 3 * 4096, a.s + (size_t)rA * kHid, a.s + (size_t)rB * kHid, s);
+        float v = a.p0[n < kNPar ? n : 0] + ief_product(ief_w + 3 * 4096, sb + pA * 8, sb + pB * 8, s, true);
         if (!ok) v = __builtin_nanf("");
         if (live && n < kNPar) {
             if (n < 3) a.cam[b * 3 + n] = v;
@@ -471,8 +504,8 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
 #endif
     }
     TRY(r->pool.alloc(&r->feats, B * kFeat));
-    TRY(r->pool.alloc(&r->h1, B * kHid));
-    TRY(r->pool.alloc(&r->h2, B * kHid));
+    TRY(r->pool.alloc(&r->h1, (B + 31) / 32 * 32 * kHid));      // blocked hand-off layout: whole blocks of 32 players
+    TRY(r->pool.alloc(&r->h2, (B + 31) / 32 * 32 * kHid));
 #undef TRY
     *out = r;
     return SPSP_OK;

@@ -21,7 +21,7 @@ namespace {
 using namespace spsp;
 
 constexpr int kSkinThreads = 256;
-constexpr int kPB = 8;   // players per skin workgroup
+constexpr int kPB = 8;   // players per skin workgroup (16 measured slower in round 3: 27.7 vs 19.0 us -- 236 VGPRs and 82 KB of LDS leave one workgroup of four waves per CU)
 
 __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ R, const float* __restrict__ betas,
                                                         const float* __restrict__ jconst,
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict_
     }
 }
 
-// Workgroup = 4 waves over the SAME 64 vertices and 8 players: wave w accumulates rows [55w, 55w+55) of the
+// Workgroup = 4 waves over the SAME 64 vertices and kPB players: wave w accumulates rows [55w, 55w+55) of the
 // 217-row blend basis (split-K: 4x more waves and 4x shorter dependent-load chains at no extra basis traffic),
-// partial sums meet in LDS, then wave w skins players 2w and 2w+1.
+// partial sums meet in LDS, then wave w skins players (kPB / 4) w .. + kPB / 4 - 1.
 __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __restrict__ basis,
                                                                  const float* __restrict__ v_template,
                                                                  const float* __restrict__ wT,
@@ -111,13 +111,14 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
         sPart[ks][p * 3 + 2][lane] = pz[p];
     }
     __syncthreads();
-    // skinning: this wave takes players 2*ks, 2*ks+1.  T = sum_k w[v][k] A_k (3x4), vert = T [v_posed; 1]
+    // skinning: this wave takes players NQ ks .. NQ ks + NQ - 1.  T = sum_k w[v][k] A_k (3x4), vert = T [v_posed; 1]
+    constexpr int NQ = kPB / 4;
     const bool vok = blockIdx.x * 64 + lane < kV;
-    float qx[2], qy[2], qz[2], ox[2], oy[2], oz[2];
+    float qx[NQ], qy[NQ], qz[NQ], ox[NQ], oy[NQ], oz[NQ];
     const float t0 = v_template[3 * v], t1 = v_template[3 * v + 1], t2 = v_template[3 * v + 2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int p = ks * 2 + q;
+    for (int q = 0; q < NQ; ++q) {
+        const int p = ks * NQ + q;
         qx[q] = t0 + ((sPart[0][p * 3][lane] + sPart[1][p * 3][lane]) + (sPart[2][p * 3][lane] + sPart[3][p * 3][lane]));
         qy[q] = t1 + ((sPart[0][p * 3 + 1][lane] + sPart[1][p * 3 + 1][lane]) + (sPart[2][p * 3 + 1][lane] + sPart[3][p * 3 + 1][lane]));
         qz[q] = t2 + ((sPart[0][p * 3 + 2][lane] + sPart[1][p * 3 + 2][lane]) + (sPart[2][p * 3 + 2][lane] + sPart[3][p * 3 + 2][lane]));
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
     for (int k = 0; k < kNJ; ++k) {
         const float w = wT[(size_t)k * kV + v];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float4* a = reinterpret_cast<const float4*>(&sA[ks * 2 + q][k * 12]);
+        for (int q = 0; q < NQ; ++q) {
+            const float4* a = reinterpret_cast<const float4*>(&sA[ks * NQ + q][k * 12]);
             const float4 r0 = a[0], r1 = a[1], r2 = a[2];
             const float rx = fmaf(r0.x, qx[q], fmaf(r0.y, qy[q], fmaf(r0.z, qz[q], r0.w)));
             const float ry = fmaf(r1.x, qx[q], fmaf(r1.y, qy[q], fmaf(r1.z, qz[q], r1.w)));
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
         }
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int p = ks * 2 + q;
+    for (int q = 0; q < NQ; ++q) {
+        const int p = ks * NQ + q;
         if (p < nb && vok) {
             float* o = verts + ((size_t)(b0 + p) * kV + v) * 3;
             o[0] = ox[q]; o[1] = oy[q]; o[2] = oz[q];

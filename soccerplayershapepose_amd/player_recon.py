@@ -181,7 +181,8 @@ def single_view_optimization_test(smpl, renderer, body_pose, global_orient, beta
     gradient of the rendered silhouette comes from the restated neural_renderer backward pass (csrc/silhouette_grad.hip,
     parity unpinned).  `renderer`: a `renderer.SilhouetteRenderer`; `silhouette` [B,512,512] (or one [512,512]) 0/1.
     Returns body_pose, global_orient, betas, translation, cam_wp, log_vars [B,2]; with return_history also loss / joints2D_l2es /
-    silhouette-metric histories [B,iters] and param_history [B,iters,231] ([cam | R | betas | log_vars] each epoch evaluated)."""
+    silhouette-metric histories [B,iters], param_history [B,iters,231] ([cam | R | betas | log_vars] each epoch evaluated) and
+    grad_history (the loss gradient there)."""
     import math
     B = betas.shape[0]
     full = torch.cat([rt.dev_f32(global_orient).reshape(B, 1, 3, 3), rt.dev_f32(body_pose).reshape(B, 23, 3, 3)], dim=1).contiguous()
@@ -206,17 +207,17 @@ def single_view_optimization_test(smpl, renderer, body_pose, global_orient, beta
     shared = 1 if tuple(tgt.shape) == (wh, wh) else 0
     if not shared and tuple(tgt.shape) != (B, wh, wh):
         raise ValueError(f'single_view_optimization_test: silhouette must be [{wh},{wh}] or [B,{wh},{wh}], got {tuple(tgt.shape)}')
-    hist = [None] * 4
+    hist = [None] * 5
     if return_history:
         hist = [torch.empty((B, cfg.iters), dtype=torch.float32, device=r.device) for _ in range(3)]
-        hist.append(torch.empty((B, cfg.iters, _abi.RECORD_FLOATS + 2), dtype=torch.float32, device=r.device))
+        hist += [torch.empty((B, cfg.iters, _abi.RECORD_FLOATS + 2), dtype=torch.float32, device=r.device) for _ in range(2)]
     r.check(r.lib.spsp_fit_silhouette(r.ctx, smpl.handle, renderer.handle, C.byref(cfg), rt.ptr(full), rt.ptr(b), rt.ptr(cam), rt.ptr(lv),
                                       rt.ptr(j2d), rt.ptr(tgt), shared, B, rt.ptr(hist[0]), rt.ptr(hist[1]), rt.ptr(hist[2]), rt.ptr(hist[3]),
-                                      r.stream()), 'spsp_fit_silhouette')
+                                      rt.ptr(hist[4]), r.stream()), 'spsp_fit_silhouette')
     translation = convert_weak_perspective_to_camera_translation_torch(cam, config.FOCAL_LENGTH, wh)
     out = SimpleNamespace(body_pose=full[:, 1:], global_orient=full[:, :1], betas=b, translation=translation, cam_wp=cam, log_vars=lv)
     if return_history:
-        out.loss_history, out.l2e_history, out.silhouette_metric_history, out.param_history = hist
+        out.loss_history, out.l2e_history, out.silhouette_metric_history, out.param_history, out.grad_history = hist
     return out
 
 

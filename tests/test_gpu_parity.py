@@ -398,9 +398,16 @@ def test_fit_with_the_silhouette_in_the_loss_against_the_autograd_oracle(smpl_gp
     """`single_view_optimization_test` (`PR/player_recon.py:1429-1557`): joints2D + silhouette loss, the criterion's two
     log-variances in the optimiser, the silhouette term reaching the camera from the second epoch on.  GPU: one chain of
     launches per epoch (csrc/fit_sil.hip); oracle: torch.autograd through the oracle SMPL and the restated neural_renderer,
-    torch.optim.Adam.  Parameters evaluated at epochs 1, 2 and 10 and after the 10th step; histories of the loss terms.
-    Tolerances: 5e-5 at epochs 1-2 (one Adam step moves every parameter by lr = 1e-3 whatever its gradient: a sign must not
-    flip), 3e-4 after ten."""
+    torch.optim.Adam.  (i) the GRADIENT of the whole loss at the first two epochs -- identical parameters, resp. parameters equal
+    to 5e-10: every piece of the backward chain (renderer, projection, SMPL, joints2D term, log-variances, camera through the
+    translation) against autograd, within 5e-3 of the largest entry of each parameter group.  (Not tighter: the two sides' SMPL
+    vertices differ in the last bit, and ONE term of the renderer's backward pass whose pixel distance falls below its eps =
+    1e-4 is worth 3.45e6 w / 1e-4 = 3e10 on a gradient of 6e12 -- measured 1e-3.  Fed identical vertices the renderer's gradient
+    agrees to 1e-7 and the SMPL reverse mode to 2e-5: the two tests above.)  (ii) the parameters after steps 1 and 2 within 5e-5 (an Adam step
+    moves every parameter by lr = 1e-3 whatever its gradient: no sign may flip); (iii) the histories of loss, joints2D_l2es and
+    silhouette metric over ten epochs, 2e-3 relative; (iv) after ten steps the parameters within 5e-3 and the log-variances within
+    3e-4: the renderer's gradient is discontinuous in the vertices (pixel ownership, 1 / dist terms), so the 5e-10 left after the
+    first step grows -- measured 2.4e-3 after nine; with identical inputs the gradient itself agrees to 1e-7 (the test above)."""
     from soccerplayershapepose_amd.player_recon import single_view_optimization_test
     from soccerplayershapepose_amd.renderer import SilhouetteRenderer
     from oracle import silhouette_grad as OG
@@ -416,15 +423,26 @@ def test_fit_with_the_silhouette_in_the_loss_against_the_autograd_oracle(smpl_gp
     np.testing.assert_allclose(out.l2e_history[0].cpu().numpy(), rec['l2e'], rtol=2e-3)
     np.testing.assert_allclose(out.silhouette_metric_history[0].cpu().numpy(), rec['sil_metric'], rtol=2e-3)
     np.testing.assert_allclose(out.loss_history[0].cpu().numpy(), rec['loss'], rtol=2e-3)
-    for ep, tol in ((1, 5e-5), (2, 5e-5), (9, 3e-4)):            # ph[ep] = the result of step ep (0-based: after ep steps)
+    gh = out.grad_history[0].cpu().numpy()
+    for ep in (1, 2):
+        want = np.concatenate([rec[f'grad_cam_{ep}'].reshape(-1), rec[f'grad_G_{ep}'].reshape(-1)])
+        gtol = 5e-3          # of the largest entry of the group (see the docstring)
+        np.testing.assert_allclose(gh[ep - 1][:12], want, rtol=0, atol=gtol * np.abs(want).max())
+        body19 = np.concatenate([gh[ep - 1][12:219].reshape(23, 9)[i] for i in list(range(6)) + list(range(8, 21))])
+        np.testing.assert_allclose(body19, rec[f'grad_body_{ep}'].reshape(-1), rtol=0, atol=gtol * np.abs(rec[f'grad_body_{ep}']).max())
+        np.testing.assert_allclose(gh[ep - 1][219:229], rec[f'grad_betas_{ep}'].reshape(-1), rtol=0, atol=gtol * np.abs(rec[f'grad_betas_{ep}']).max())
+        np.testing.assert_allclose(gh[ep - 1][229:231], rec[f'grad_lv_{ep}'], rtol=1e-4)
+        if ep == 1:
+            np.testing.assert_allclose(gh[0][:3], rec['grad_cam_1'].reshape(-1), rtol=1e-4)     # joints2D term alone: exact
+    for ep, tol in ((1, 5e-5), (2, 5e-5), (9, 5e-3)):            # ph[ep] = the result of step ep (0-based: after ep steps)
         want = np.concatenate([rec['cam'][ep - 1].reshape(-1), rec['G'][ep - 1].reshape(-1), rec['body'][ep - 1].reshape(-1),
                                rec['betas'][ep - 1].reshape(-1), rec['lv'][ep - 1].reshape(-1)])
         dev_ = np.abs(ph[ep] - want)
         print(f'silhouette fit, after step {ep}: max parameter deviation {dev_.max():.2e} (parameter {int(dev_.argmax())}), {int((dev_ > tol).sum())} beyond {tol}')
         assert dev_.max() < tol, f'after step {ep}: {dev_.max()} at parameter {int(dev_.argmax())}'
     body, Gm, be, ca, lvj, lvs = ref['last']
-    assert (out.body_pose[0].cpu() - body[0]).abs().max().item() < 3e-4 and (out.cam_wp[0].cpu() - ca[0]).abs().max().item() < 3e-4
-    assert (out.betas[0].cpu() - be[0]).abs().max().item() < 3e-4 and (out.global_orient[0].cpu() - Gm[0]).abs().max().item() < 3e-4
+    assert (out.body_pose[0].cpu() - body[0]).abs().max().item() < 5e-3 and (out.cam_wp[0].cpu() - ca[0]).abs().max().item() < 5e-3
+    assert (out.betas[0].cpu() - be[0]).abs().max().item() < 5e-3 and (out.global_orient[0].cpu() - Gm[0]).abs().max().item() < 5e-3
     np.testing.assert_allclose(out.log_vars[0].cpu().numpy(), [lvj, lvs], atol=3e-4)
     assert rec['sil_metric'][-1] < rec['sil_metric'][0]           # and the silhouette term does pull the mesh into the target
 
