@@ -21,7 +21,7 @@
 //                        packed (depth bits << 32 | copy index) under ds_min_u64 -- the smallest depth wins, ties go to the
 //                        lower copy index, exactly the sequential rule of the reference loop                [B x 256 tiles]
 //   sil_value_kernel     2 x 2 samples -> p, the terms of S (fixed-order block sums), optional image
-//   sil_backward_kernel  one thread per (mesh, face): the three edges x two axes scans -> d/d(x_n, y_n) of its three vertices
+//   sil_backward_kernel  one wave per (mesh, face): the three edges x two axes scans, d1 over the lanes -> d/d(x_n, y_n) of its three vertices
 //   sil_vertex_kernel    per vertex: fixed-order sum over its incident face corners (CSR built at load), projection backward,
 //                        block partial sums of dL/dt
 // Same fp32 operations in the same order as the CPU twin wherever a comparison decides something (coverage, ownership,
@@ -166,13 +166,17 @@ __global__ void sil_sum_kernel(const float* __restrict__ partial, int nblk, int 
     out[(size_t)b * ostride] = s;
 }
 
-// backward_pixel_map: one thread per (mesh, face); gface [B][F][3 corners in the face's ORIGINAL vertex order][2]
-__global__ __launch_bounds__(64) void sil_backward_kernel(const float4* __restrict__ proj, const int* __restrict__ faces, int F, int is,
-                                                          const int* __restrict__ owner, const uint8_t* __restrict__ target,
-                                                          size_t target_stride, const float* __restrict__ weight, int wstride, float ga_t0, float ga_t1,
-                                                          float* __restrict__ gface) {
+// backward_pixel_map: one WAVE per (mesh, face); gface [B][F][3 corners in the face's ORIGINAL vertex order][2].
+// The walk over edges, axes and columns d0 is wave-uniform (every lane computes it); the scans along d1 -- up to the image
+// border for the out-part: a thread per face spent its time in 1024-step loops, 50 ms per 32 meshes -- are spread over the 64
+// lanes, each lane keeps its own partial sums, one butterfly reduction per face at the end.
+__global__ __launch_bounds__(256) void sil_backward_kernel(const float4* __restrict__ proj, const int* __restrict__ faces, int F, int is,
+                                                           const int* __restrict__ owner, const uint8_t* __restrict__ target,
+                                                           size_t target_stride, const float* __restrict__ weight, int wstride, float ga_t0, float ga_t1,
+                                                           float* __restrict__ gface) {
 #pragma clang fp contract(off)
-    const int f = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (f >= F) return;
     const FrontFace t = front_copy(proj + (size_t)b * kRV, faces, f, F);
     const int* ob = owner + (size_t)b * is * is;
@@ -180,11 +184,11 @@ __global__ __launch_bounds__(64) void sil_backward_kernel(const float4* __restri
     const int wh = is / 2;
     const float w = weight[(size_t)b * wstride];
     const float fis = (float)is, two_over_is = 2.f / fis;
-    float g[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};            // [corner of the front copy][x, y]
+    float g[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};            // this lane's share, [corner of the front copy][x, y]
     float px[3], py[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { px[k] = 0.5f * (t.x[k] * fis + fis - 1.f); py[k] = 0.5f * (t.y[k] * fis + fis - 1.f); }
-    // alpha, owner and dL/dalpha of sample (column d0, row d1) in scan coordinates of `axis`
+    // owner and dL/dalpha of sample (column d0, row d1) in scan coordinates of `axis`
     auto at = [&](int axis, int d0, int d1, int& own, float& ga) {
         const int xi = axis == 0 ? d0 : d1, yi = axis == 0 ? d1 : d0;
         own = ob[(size_t)yi * is + xi];
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(64) void sil_backward_kernel(const float4* __restri
             const int direction = axis == 0 ? (a0 < a1 ? -1 : 1) : (a0 < a1 ? 1 : -1);
             const int d0_from = max((int)ceilf(fminf(a0, a1)), 0);
             const int d0_to = (int)fminf(fmaxf(a0, a1), (float)(is - 1));
+            float acc0 = 0.f, acc1 = 0.f;
             for (int d0 = d0_from; d0 <= d0_to; ++d0) {
                 const float fd0 = (float)d0;
                 const float cross = (b1 - b0) / (a1 - a0) * (fd0 - a0) + b0;
@@ -214,7 +219,6 @@ __global__ __launch_bounds__(64) void sil_backward_kernel(const float4* __restri
                 const float alpha_in = own_in >= 0 ? 1.f : 0.f, alpha_out = own_out >= 0 ? 1.f : 0.f;
                 const bool m0 = a1 != fd0, m1 = a0 != fd0;
                 const float r0 = (a1 - a0) / (a1 - fd0), r1 = (a1 - a0) / (fd0 - a0);
-                float acc0 = 0.f, acc1 = 0.f;
                 auto pull = [&](int d1, float diff) {
                     if (!(diff > 0.f)) return;
                     const float off = (float)d1 - cross;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64) void sil_backward_kernel(const float4* __restri
                 if (own_in == t.fn) {                             // out-part: from the out-pixel to the image border
                     const int lim = direction > 0 ? is - 1 : 0;
                     const int lo = max(min(d1_out, lim), 0), hi = min(max(d1_out, lim), is - 1);
-                    for (int d1 = lo; d1 <= hi; ++d1) {
+                    for (int d1 = lo + lane; d1 <= hi; d1 += 64) {
                         int own; float ga;
                         at(axis, d0, d1, own, ga);
                         pull(d1, ((own >= 0 ? 1.f : 0.f) - alpha_in) * ga);
@@ -237,23 +241,35 @@ __global__ __launch_bounds__(64) void sil_backward_kernel(const float4* __restri
                     if (isfinite(cross2)) {
                         const int lim = direction > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
                         const int lo = max(min(d1_in, lim), 0), hi = min(max(d1_in, lim), is - 1);
-                        for (int d1 = lo; d1 <= hi; ++d1) {
+                        for (int d1 = lo + lane; d1 <= hi; d1 += 64) {
                             int own; float ga;
                             at(axis, d0, d1, own, ga);
                             if (own == t.fn) pull(d1, (1.f - alpha_out) * ga);
                         }
                     }
                 }
-                g[i0][1 - axis] -= acc0;
-                g[i1][1 - axis] -= acc1;
             }
+            g[i0][1 - axis] -= acc0;
+            g[i1][1 - axis] -= acc1;
         }
     }
-    float* o = gface + ((size_t)b * F + f) * 6;
+    // six sums over the lanes (fixed butterfly order: reproducible from run to run)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int orig = t.rev ? 2 - k : k;                          // corner of the ORIGINAL vertex order
-        o[orig * 2] = g[k][0]; o[orig * 2 + 1] = g[k][1];
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float v = g[k][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            g[k][c] = v;
+        }
+    if (lane == 0) {
+        float* o = gface + ((size_t)b * F + f) * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int orig = t.rev ? 2 - k : k;                      // corner of the ORIGINAL vertex order
+            o[orig * 2] = g[k][0]; o[orig * 2 + 1] = g[k][1];
+        }
     }
 }
 
@@ -351,7 +367,7 @@ int silhouette_loss_grad_impl(spsp_ctx* ctx, spsp_rasterizer* h, const float* ve
         // dL/dp of a pixel with t = 0 / t = 1, a quarter of it per sample (before the weight): -(ln(t + 1e-6) - ln(1 - t + 1e-6)) / 4
         const float A0 = std::log(0.f + 1e-6f), B0 = std::log(1.f - 0.f + 1e-6f), A1 = std::log(1.f + 1e-6f), B1 = std::log(1.f - 1.f + 1e-6f);
         const float ga_t0 = -(A0 - B0) * 0.25f, ga_t1 = -(A1 - B1) * 0.25f;
-        sil_backward_kernel<<<dim3((h->F + 63) / 64, B), 64, 0, st>>>(proj, h->faces, h->F, is, h->owner, target, tgs, weight, wstride, ga_t0, ga_t1, h->gface);
+        sil_backward_kernel<<<dim3((h->F + 3) / 4, B), 256, 0, st>>>(proj, h->faces, h->F, is, h->owner, target, tgs, weight, wstride, ga_t0, ga_t1, h->gface);
         sil_vertex_kernel<<<dim3(nvb, B), 256, 0, st>>>(verts, translation, tstride, focal, wh, h->adj_ptr, h->adj_idx, h->gface, h->F, grad_verts, h->tpart);
         if (grad_translation) sil_tsum_kernel<<<(B * 3 + 63) / 64, 64, 0, st>>>(h->tpart, nvb, B, grad_translation, gstride);
     }
