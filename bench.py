@@ -49,7 +49,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='crops per GPU per step')
     ap.add_argument('--fit', default='pose_shape', choices=['pose_shape', 'camera'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -62,11 +62,7 @@ def parse(argv=None):
                     help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
     ap.add_argument('--rehearse-dist', action='store_true',
                     help='run the N>1 code path (RCCL communicators, per-step all-gather, barriers) even with one rank')
-    ap.add_argument('--condition-ms', type=float, default=400.0,
-                    help='untimed: the pipelined steps run for this long before the --warmup steps, so that the timed region starts with '
-                         'the GPU out of its idle power state (the set-up before it -- per-kernel pass with a sync per step, graph capture '
-                         '-- leaves the GPU idle for hundreds of ms; measured in one process: the first 60 ms after such a pause run at '
-                         '102 k players/s, the following at 121 k).  0 = off')
+    ap.add_argument('--probe', action='store_true', help=argparse.SUPPRESS)       # diagnostic: re-time the pipeline after the timed region (stderr)
     ap.add_argument('--inputs', type=int, default=0,
                     help='distinct resident input batches rotated through the steps (0 = one per pipeline slot, at least 4): every step '
                          'reads another 80 MB buffer, so the input is streamed from HBM and not re-read from the Infinity Cache')
@@ -314,7 +310,7 @@ def main():
         mk_s = lambda: SMPL(model, max_batch=B)
         return PlayerPipeline(mk_r, mk_s, dev, depth=max(1, args.depth), streams=streams)
 
-    pipe = make_pipe(args.precision)
+    pipe = make_pipe(args.precision, streams=[torch.cuda.Stream(device=dev) for _ in range(max(1, args.depth))] if os.environ.get('BENCH_UPFRONT_STREAMS') else None)
     reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl
     r = rt.get(dev)
     lanes = max(1, min(args.exchange_lanes, len(pipe.slots)))
@@ -435,12 +431,8 @@ def main():
             for _ in range(math.lcm(len(pipe_.slots), n_inputs)):      # every (slot, input batch) pair that will occur
                 step_fn()
             torch.cuda.synchronize()
-        # untimed: clock conditioning (see --condition-ms), then the W warm-up steps of the contract -- through the very path that
-        # is timed, with nothing but the barrier + synchronize between them and the timed region
-        for i in range(int(args.condition_ms / 0.33)):      # a step takes ~0.33 ms; a COUNT, so that every rank issues the same collectives
-            step_fn()
-            if i % 8 == 7:
-                torch.cuda.synchronize()
+        # untimed: the W warm-up steps of the contract -- through the very path that is timed, with nothing but the barrier +
+        # synchronize between them and the timed region
         for _ in range(args.warmup):
             step_fn()
         if not args.graphs and select_id is not None:
@@ -463,6 +455,20 @@ def main():
         return el.item(), out_
 
     elapsed, out = timed(step, pipe, kernels_iso[dom]['id'])
+    if args.probe and args.graphs:
+        for label, fn in (('step()', step), ('submit(natives[i % 4], one target set)', None)):
+            rates = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for i_ in range(args.steps):
+                    if fn is not None:
+                        fn()
+                    else:
+                        pipe.submit(inputs[i_ % n_inputs].native, inputs[i_ % n_inputs].tgt, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+                torch.cuda.synchronize()
+                rates.append(round(B * args.steps / (time.perf_counter() - t0_)))
+            print(f'[probe] {label}: {rates} players/s (timed region: {B * args.steps / elapsed:.0f})', file=sys.stderr)
     if use_dist:        # every rank holds every player's record, in shard order
         assert out.gathered.shape == (world * B, 229) and torch.equal(out.gathered[rank * B:(rank + 1) * B, :3], out.cam)
     assert torch.isfinite(out.vertices).all() and out.vertices.abs().max().item() > 0.1
@@ -552,7 +558,6 @@ def main():
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs), 'input_batches_rotated': n_inputs,
-                       'clock_conditioning_ms': args.condition_ms,
                        'proxy_built_on_gpu': bool(args.from_detections),
                        'exchange': (exchange.describe() if exchange else None)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE

@@ -47,7 +47,7 @@ int launch_conv_ring(const ConvArgs& a, RingTile tile, hipStream_t stream);
 
 // third generation (conv_patch.hip): 3x3 stride-1 convs with an LDS-resident input patch, 256 / 128 px x 64 / 32 ch per workgroup
 bool conv_patch_supported(const ConvArgs& a);
-int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, hipStream_t stream);
+int launch_conv_patch(const ConvArgs& a, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, bool producer_waves, hipStream_t stream);
 
 int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels = 64);   // XCDs along the channel blocks for the fewest fabric bytes
 

@@ -122,9 +122,17 @@ struct Geo {
 // One workgroup: TPIX pixels x (16 NCT) channels.  grid = (M/TPIX) * (N / (16 NCT)).
 // NCT = channel tiles (of 16) per wave: 4 (64-channel blocks) or 2 (32-channel blocks -- twice the workgroups, for layer4 whose
 // 128 blocks of 128 pixels x 64 channels fill half the chip and whose 776 KB of staging per workgroup, not its MFMAs, set its time).
-template <bool W8, bool F16, bool DB, int NPG, int NG, int NCT = 4>
-__global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs a) {
+//
+// PROD (round 3): FOUR MORE wavefronts, one per SIMD, that do nothing but issue the LDS-DMA pieces (patches and weight slabs).  A
+// global_load_lds occupies its wave's instruction stream for ~60-180 cycles (the address path takes the 64 lanes in quarters),
+// and with ONE wave per SIMD the matrix pipe drains meanwhile: ~100 pieces per wave and tile = a quarter of a workgroup's
+// life.  The producers wait (counted vmcnt) for their own pieces in front of the very barriers the consumers already have, so
+// the consumers' group top is the bare barrier; they end after the K loop (a barrier counts the surviving waves only).
+// The accumulating waves then share their SIMD's register file with a producer: <= 256 VGPRs.
+template <bool W8, bool F16, bool DB, int NPG, int NG, int NCT = 4, bool PROD = false>
+__global__ __launch_bounds__(128 * NPG + (PROD ? 256 : 0)) void conv3x3_patch_kernel(const ConvArgs a) {
     using G = Geo<W8, NPG>;
+    static_assert(!PROD || NPG == 2, "producer waves: four accumulating waves, the pieces are split four ways as without them");
     constexpr int PW = G::PW, kNS = 3 * NG, NW = G::NW, KS = 2;   // NG = ring depth in groups of three slabs (2 or 3)
     constexpr int NCH = 16 * NCT, kWStage = NCH * 128;            // (shadows the file-level constant)
     static_assert(NG == 2 || NG == 3, "ring depth");
@@ -136,8 +144,10 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     const int tid = threadIdx.x, lane = tid & 63;
     CS_WG(0)
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = PROD && wave_id >= NW;                   // (wave-uniform)
+    const int dma_id = PROD ? wave_id - NW : wave_id;              // which share of the DMA pieces this wave issues
     const int wave = wave_id & (NPG - 1);                          // which 64 pixels of the tile
-    const int kw = wave_id / NPG;                                  // KS == 2: which 32-deep half of every K-step
+    const int kw = (wave_id / NPG) & 1;                            // KS == 2: which 32-deep half of every K-step
     const int W = a.Wo;                                            // == Ho, == input W (stride 1)
     const int mt = a.M / G::TPIX, nb = a.N / NCH;
     int m_tile, n_blk;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     int p_src[G::DPW];                                             // element offsets into a.in (chunk 0)
 #pragma unroll
     for (int i = 0; i < G::DPW; ++i) {
-        int p = wave_id + NW * i;
+        int p = dma_id + NW * i;
         p = p < G::NDMA ? p : G::NDMA - 1;
         int q = p * 8 + drow;
         q = q < G::NPIX ? q : G::NPIX - 1;                         // tail lanes re-read the last pixel (harmless)
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     auto issue_patch = [&](int ch, int pbuf = 0) {
 #pragma unroll
         for (int i = 0; i < G::DPW; ++i) {
-            int p = wave_id + NW * i;
+            int p = dma_id + NW * i;
             p = p < G::NDMA ? p : G::NDMA - 1;       // every wave issues exactly DPW pieces (counted vmcnt waits): the surplus repeats the last one
             dma16(in_ptr + p_src[i] + (ch0 + ch) * 64, patch0 + pbuf * G::PATCH + p * 1024);
         }
@@ -203,12 +213,12 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     const uint16_t* w_src[LPS];
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
-        const int row = (wave_id * LPS + i) * 8 + drow;
+        const int row = (dma_id * LPS + i) * 8 + drow;
         w_src[i] = w_ptr + (size_t)(n_blk + acc_channel(row >> 4, row & 15)) * Ktot + ((dchunk ^ (row & 7)) * 8);   // LDS row 'row' holds that output channel
     }
     auto issue_w = [&](int g, int buf) {
 #pragma unroll
-        for (int i = 0; i < LPS; ++i) dma16(w_src[i] + (size_t)g * 64, ring + buf * kWStage + (wave_id * LPS + i) * 1024);
+        for (int i = 0; i < LPS; ++i) dma16(w_src[i] + (size_t)g * 64, ring + buf * kWStage + (dma_id * LPS + i) * 1024);
     };
 
     f32x4 acc[NCT][4];
@@ -335,7 +345,6 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
 
     CSTAMP(0);
     CS_DECL
-    issue_patch(0);
     {
         const int ngroups = 3 * nchunks;
         auto issue_group = [&](int g) {
@@ -343,8 +352,32 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
 #pragma unroll
             for (int t = 0; t < 3; ++t) issue_w((ROWS ? t * 3 + gr : gr * 3 + t) * nch_tot + ch0 + gch, (g % NG) * 3 + t);   // ROWS: taps (ky = t, dx = gr)
         };
-        issue_group(0);
-        if (NG == 3 && ngroups > 1) issue_group(1);
+        if (!PROD || producer) {
+            issue_patch(0);
+            issue_group(0);
+            if (NG == 3 && ngroups > 1) issue_group(1);
+        }
+        if constexpr (PROD) {
+            if (producer) {
+                // the DMA side of SPSP_GROUP below, group by group: the same counted waits in front of the same barriers
+                for (int g = 0; g < ngroups; ++g) {
+                    const int ch = g / 3, R = g - ch * 3;
+                    if (NG == 2 || g + 1 >= ngroups) wait_vmcnt<0>();
+                    else if (DB && R == 1 && ch + 1 < nchunks) wait_vmcnt<3 * LPS + G::DPW>();
+                    else wait_vmcnt<3 * LPS>();
+                    __builtin_amdgcn_s_barrier();
+                    if (!DB && R == 0 && ch > 0) {
+                        issue_patch(ch);
+                        if (g + NG - 1 < ngroups) { issue_group(g + NG - 1); wait_vmcnt<3 * LPS>(); } else wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                    } else {
+                        if (DB && R == 0 && ch + 1 < nchunks) issue_patch(ch + 1, (ch + 1) & 1);
+                        if (g + NG - 1 < ngroups) issue_group(g + NG - 1);
+                    }
+                }
+                return;
+            }
+        }
         // At the top of group g its slabs (requested two groups ago) must have landed; what this wave issued after them may
         // stay in flight: the slabs of group g+1 and, with two patch buffers, the next chunk's patch when that was
         // requested one group ago (at a chunk's first group).
@@ -353,7 +386,8 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         const int g_ = (CH) * 3 + (R);                                                                    \
         const uint32_t pboff_ = DB ? ((CH) & 1) * G::PATCH : 0;   /* this chunk's patch buffer */          \
         CS_BEGIN                                                                                          \
-        if (NG == 2 || g_ + 1 >= ngroups) wait_vmcnt<0>();                                                \
+        if (PROD) {}                                              /* (the producers wait for the pieces) */ \
+        else if (NG == 2 || g_ + 1 >= ngroups) wait_vmcnt<0>();                                           \
         else if (DB && (R) == 1 && (CH) + 1 < nchunks) wait_vmcnt<3 * LPS + G::DPW>();                    \
         else wait_vmcnt<3 * LPS>();                                                                       \
         CS_MID                                                                                            \
@@ -362,17 +396,17 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
         if (!DB && (R) == 0 && (CH) > 0) {                                                                \
             /* one patch buffer, chunk boundary: every wave is past its last read of the old patch; refill it, run */ \
             /* the pending MFMAs of the previous tap underneath, then wait for the patch (older than the slabs) */ \
-            issue_patch(CH);                                                                              \
-            if (g_ + NG - 1 < ngroups && !CS_NODMA) issue_group(g_ + NG - 1);                                       \
+            if (!PROD) issue_patch(CH);                                                                   \
+            if (!PROD && g_ + NG - 1 < ngroups && !CS_NODMA) issue_group(g_ + NG - 1);                    \
             SPSP_MFMA_SET(((P0) & 1) ^ 1, ROWS ? ((P0) & 1) ^ 1 : ((P0) & 1) ^ 1, ROWS ? 2 : 0)           \
-            if (g_ + NG - 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();                       \
+            if (PROD) {} else if (g_ + NG - 1 < ngroups) wait_vmcnt<3 * LPS>(); else wait_vmcnt<0>();     \
             __builtin_amdgcn_s_barrier();                                                                 \
             SPSP_STEP(0, 0, P0, true)                                                                     \
         } else {                                                                                          \
             /* two patch buffers, first group of a chunk: every wave is past its reads of chunk CH-1, whose buffer */ \
             /* now takes chunk CH+1 -- it has the nine taps of this chunk to land (no wait at chunk boundaries)    */ \
-            if (DB && (R) == 0 && (CH) + 1 < nchunks && !CS_NODMA) issue_patch((CH) + 1, ((CH) + 1) & 1); \
-            if (g_ + NG - 1 < ngroups && !CS_NODMA) issue_group(g_ + NG - 1);                                       \
+            if (!PROD && DB && (R) == 0 && (CH) + 1 < nchunks && !CS_NODMA) issue_patch((CH) + 1, ((CH) + 1) & 1); \
+            if (!PROD && g_ + NG - 1 < ngroups && !CS_NODMA) issue_group(g_ + NG - 1);                    \
             SPSP_STEP(R, 0, P0, (R) == 0 && (CH) == 0)                                                    \
         }                                                                                                 \
         if ((R) == 1 && (CH) == 0) { CSTAMP(10); }                                                        \
@@ -538,7 +572,7 @@ __global__ __launch_bounds__(128 * NPG) void conv3x3_patch_kernel(const ConvArgs
     CS_WG(1)
 }
 
-template <bool W8, bool F16, bool DB, int NPG, int NG, int NCT = 4>
+template <bool W8, bool F16, bool DB, int NPG, int NG, int NCT = 4, bool PROD = false>
 int launch_t(const ConvArgs& a, hipStream_t st) {
     using G = Geo<W8, NPG>;
     constexpr size_t lds_need = (size_t)3 * NG * (NCT * 16 * 128) + (DB ? 2 : 1) * G::PATCH;
@@ -546,7 +580,7 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = lds_need > lds_xch ? lds_need : lds_xch;
     static_assert(lds <= 160 * 1024, "one CU has 160 KB of LDS");
     static_assert(!W8 || NPG % 2 == 0, "8 x 8 maps are tiled in interleaved pairs of images");
-    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT>>((int)lds)));
+    SPSP_TRY((ensure_dynamic_lds<&conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT, PROD>>((int)lds)));
     const int grid = (a.M / G::TPIX) * (a.N / (16 * NCT));
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
@@ -557,15 +591,15 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         (void)hipMemset(b.dbg, 0, nd * sizeof(unsigned long long));
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT>), dim3(grid), dim3(64 * G::NW), (unsigned)lds, st, e0, e1, 0, b);
+        hipExtLaunchKernelGGL((conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT, PROD>), dim3(grid), dim3(64 * (G::NW + (PROD ? 4 : 0))), (unsigned)lds, st, e0, e1, 0, b);
         (void)hipDeviceSynchronize();
         float kms = 0.f;
         (void)hipEventElapsedTime(&kms, e0, e1);
         std::vector<unsigned long long> hv(nd);
         (void)hipMemcpy(hv.data(), b.dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         const unsigned long long* h = hv.data();
-        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d,NG=%d> chunks=%d wgs=%d: K loop %llu (of which weight wait %llu, barrier %llu) | residual loads + K-half exchange %llu | epilogue + stores %llu | total %llu cycles; one step (16 MFMAs) %llu, the next %llu\n",
-                (int)W8, (int)DB, NPG, NG, a.chunks, grid, h[4] - h[0], h[8], h[9], h[5] - h[4], h[6] - h[5], h[6] - h[0], h[11] - h[10], h[12] - h[11]);
+        fprintf(stderr, "patch<W8=%d,DB=%d,NPG=%d,NG=%d%s> chunks=%d wgs=%d: K loop %llu (of which weight wait %llu, barrier %llu) | residual loads + K-half exchange %llu | epilogue + stores %llu | total %llu cycles; one step (16 MFMAs) %llu, the next %llu\n",
+                (int)W8, (int)DB, NPG, NG, PROD ? ",PROD" : "", a.chunks, grid, h[4] - h[0], h[8], h[9], h[5] - h[4], h[6] - h[5], h[6] - h[0], h[11] - h[10], h[12] - h[11]);
         {
             unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
             double dur = 0;
@@ -583,14 +617,14 @@ int launch_t(const ConvArgs& a, hipStream_t st) {
         return SPSP_OK;
     }
 #endif
-    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT>, dim3(grid), dim3(64 * G::NW), lds, st, a);
+    launch_kernel(&conv3x3_patch_kernel<W8, F16, DB, NPG, NG, NCT, PROD>, dim3(grid), dim3(64 * (G::NW + (PROD ? 4 : 0))), lds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;
 }
 
-template <bool W8, bool DB, int NPG, int NG, int NCT = 4>
+template <bool W8, bool DB, int NPG, int NG, int NCT = 4, bool PROD = false>
 int launch(const ConvArgs& a, hipStream_t st) {
-    return a.f16 ? launch_t<W8, true, DB, NPG, NG, NCT>(a, st) : launch_t<W8, false, DB, NPG, NG, NCT>(a, st);
+    return a.f16 ? launch_t<W8, true, DB, NPG, NG, NCT, PROD>(a, st) : launch_t<W8, false, DB, NPG, NG, NCT, PROD>(a, st);
 }
 
 }  // namespace
@@ -619,7 +653,7 @@ int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels) {
     return best;      // 0: no split fits (the kernel falls back to channel-block-fastest over the whole grid)
 }
 
-int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, hipStream_t stream) {
+int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, bool producer_waves, hipStream_t stream) {
     SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
     SPSP_REQUIRE(!a0.pool_out || a0.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
     SPSP_REQUIRE(tile_pixels == 256 || tile_pixels == 128, "conv_patch: tile of %d pixels", tile_pixels);
@@ -629,6 +663,11 @@ int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixel
     ConvArgs a = a0;
     a.xcd_n = conv_patch_xcd_n(a, tile_pixels, block_channels);
     const bool db = two_patch_buffers, w8 = a.Wo == 8;
+    if (producer_waves) {
+        SPSP_REQUIRE(tile_pixels == 128 && ring_groups == 3 && db, "conv_patch: producer waves come with 128-pixel tiles, a three-group ring and two patch buffers");
+        if (block_channels == 32) return launch<true, true, 2, 3, 2, true>(a, stream);
+        return w8 ? launch<true, true, 2, 3, 4, true>(a, stream) : launch<false, true, 2, 3, 4, true>(a, stream);
+    }
     if (block_channels == 32) return db ? launch<true, true, 2, 3, 2>(a, stream) : launch<true, false, 2, 3, 2>(a, stream);
     // (8 x 8 maps, 256-pixel tiles: two 50 KB patches do not fit beside a three-group ring -> one patch buffer)
 #define SPSP_PICK(W8, DB, NPG, NG) return launch<W8, DB, NPG, NG>(a, stream)

@@ -1,8 +1,9 @@
-// GPU driver of the reprojection fit: one 256-thread workgroup (4 wavefronts) per player, all iterations in one
-// launch, state in LDS (13 KB: the model constants a lane needs live in its registers, so a fit workgroup fits on a CU next to
-// a 148 KB convolution workgroup of another stream), Adam moments in registers (one parameter per lane).  The arithmetic lives in fit_core.hpp (shared with the
-// host emulation used by the CPU tests).  Latency-bound by design (10 workgroup barriers / iteration);
-// players are independent, so a batch fills one CU per player.
+// GPU driver of the reprojection fit: one 256-thread workgroup (4 wavefronts) per player, all iterations in one launch, state in
+// LDS (14 KB), Adam moments and the model constants a lane multiplies with in registers (one parameter per lane).  The
+// arithmetic lives in fit_core.hpp (shared with the host emulation used by the CPU tests).  Latency-bound by design: ten
+// workgroup barriers per iteration, the two tree sweeps as register-resident walks inside wavefront 0.  Players are
+// independent, so a batch holds one CU per player.  (Four players per workgroup -- 8 CUs per batch -- was built and measured in
+// round 3: the fit got 1.5 x longer and the four-slot pipeline slower, because a slot's stream waits for its fit)
 #include <cmath>
 #include <cstdlib>
 
@@ -22,7 +23,9 @@ __device__ __forceinline__ void wave_phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const float* __restrict__ fitc,
+// WALK: the two tree sweeps as barrier-free walks (fit_core.hpp; every SMPL tree) instead of level by level inside wavefront 0.
+template <bool WALK>
+__global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const uint32_t* __restrict__ walk, const float* __restrict__ fitc,
                                                  const int* __restrict__ parents, const int* __restrict__ level_joints,
                                                  const int* __restrict__ level_start, const int* __restrict__ child_start,
                                                  const int* __restrict__ child_list, float* __restrict__ R,
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
     float* bb = betas + (size_t)b * 10;
     float* cb = cam + (size_t)b * 3;
     fit_init(s, r, lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb, cb,
-             joints2d + (size_t)b * 34, P.param_mask);
+             joints2d + (size_t)b * 34, P.param_mask, WALK ? walk : nullptr);
     __syncthreads();
     float* lh = loss_hist ? loss_hist + (size_t)b * P.iters : nullptr;
     float* eh = l2e_hist ? l2e_hist + (size_t)b * P.iters : nullptr;
@@ -63,31 +66,45 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         fit_p1(s, r, lane);                       __syncthreads();
         STAMP(1);
         fit_p2(s, lane);                          __syncthreads();
-        if (wave0) {
+        if constexpr (WALK) { if (wave0) fit_chain_walk(s, r, lane); }
+        else if (wave0) {
+            uint32_t ql[kMaxLevels];
 #pragma unroll
-            for (int l = 1; l < kMaxLevels; ++l)       // static l: the per-lane role tables stay in registers
-                if (l < L) { fit_chain_level(s, r, l); wave_phase_fence(); }
+            for (int l = 1; l < kMaxLevels; ++l) ql[l] = r.lvl[l];
+#pragma unroll
+            for (int l = 1; l < kMaxLevels; ++l)       // static l: the role words stay in registers
+                if (l < L) { fit_chain_level(s, r, ql[l]); wave_phase_fence(); }
         }
         STAMP(2);
         __syncthreads();
         STAMP(3);
         fit_p4(s, r, lane);                       __syncthreads();
         STAMP(4);
-        if (wave0) { fit_p5(s, lane); wave_phase_fence(); fit_p6(s, r, lane, P); }
+        if (wave0) fit_p6(s, r, lane, P, true);      // (P5 folded in)
         STAMP(5);
         __syncthreads();
         fit_p7(s, r, lane);                       __syncthreads();
         STAMP(6);
-        if (wave0) {
+        if constexpr (WALK) {
+            if (wave0) {
+                fit_p8(s, lane, P, it, lh, eh);
+                fit_reverse_walk_a(s, r, lane);
+                wave_phase_fence();
+                fit_reverse_walk_b(s, r, lane);
+            }
+        } else if (wave0) {
+            uint32_t ql[kMaxLevels];
+#pragma unroll
+            for (int l = 0; l < kMaxLevels - 1; ++l) ql[l] = r.lvl[l];
             fit_p8(s, lane, P, it, lh, eh);
             wave_phase_fence();
 #pragma unroll
             for (int l = kMaxLevels - 2; l >= 0; --l)
-                if (l <= L - 2) { fit_reverse_level(s, r, l); wave_phase_fence(); }
+                if (l <= L - 2) { fit_reverse_level(s, r, ql[l]); wave_phase_fence(); }
         }
         STAMP(7);
         __syncthreads();
-        fit_p10(s, r, lane);                   __syncthreads();
+        fit_p10(s, r, lane, WALK);                   __syncthreads();
         STAMP(8);
         fit_p11(s, r, lane);                      __syncthreads();
         STAMP(9);
@@ -161,14 +178,18 @@ int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg,
     P.weight = std::exp(-P.log_var);
     P.select_mode = cfg->select_mode;
     P.num_levels = s->num_levels;
+    P.walk_nb = s->walk_nb;
     ProfScope ps(ctx, kKFit, as_stream(stream), true);
     unsigned long long* dbg = nullptr;
 #ifdef SPSP_FIT_STAMPS
     if (getenv("SPSP_FIT_DEBUG")) (void)hipMalloc(&dbg, 16 * sizeof(unsigned long long));
 #endif
-    launch_kernel(&fit_kernel, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->fitc, s->parents, s->level_joints, s->d_level_start,
-                                                s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist,
-                                                l2e_hist, param_hist, dbg);
+#define SPSP_FIT_LAUNCH(WALK)                                                                                                        \
+    launch_kernel(&fit_kernel<WALK>, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,  \
+                  s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, dbg)
+    // (the level sweeps remain for models whose tree is not SMPL's; the variable is the A/B switch of tests and tools)
+    if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS")) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
+#undef SPSP_FIT_LAUNCH
     if (dbg) {
         unsigned long long h[16];
         (void)hipDeviceSynchronize();

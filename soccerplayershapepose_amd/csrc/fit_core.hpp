@@ -23,6 +23,7 @@
 //                    dL/dvp_v = sum_k w_vk Rw_k^T h_v,   dL/dbeta = S5^T dvp + JS^T dJ
 #pragma once
 #include <math.h>
+#include <string.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -39,7 +40,7 @@ namespace spsp {
 constexpr int kFitLanes = 256;                // lanes (threads) cooperating on one player
 constexpr int kNumPrm = SPSP_RECORD_FLOATS;   // 229: [cam(3) | R(216) | betas(10)]
 constexpr int kPrmR = 3, kPrmBeta = 219;
-constexpr int kMaxLevels = 12;                // tree depth limit (SMPL: 9 levels); checked at spsp_smpl_load
+constexpr int kMaxLevels = 9;                 // tree depth limit = the 9 levels of the SMPL tree; checked at spsp_smpl_load (smpl_host.hpp)
 
 // fit joint i reads output joint kFitSrc[i] (PR/config.py:38); < 24: chain joint, >= 24: face vertex (idx-24)
 #define SPSP_FIT_SRC {24, 26, 25, 28, 27, 16, 17, 18, 19, 20, 21, 1, 2, 4, 5, 7, 8}
@@ -48,6 +49,12 @@ constexpr int kMaxLevels = 12;                // tree depth limit (SMPL: 9 level
 #define SPSP_UNROLL _Pragma("unroll")
 #else
 #define SPSP_UNROLL
+#endif
+// keeps the optimiser from hoisting what is derived from a loop-invariant register out of the iteration loop (GPU only)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPSP_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define SPSP_OPAQUE(x) (void)(x)
 #endif
 
 // four consecutive floats from a 16-byte aligned address: ONE ds_read_b128 on the GPU (a lone wave issues LDS
@@ -78,13 +85,14 @@ struct FitParams {           // kernel arguments (plain data)
     float log_var, weight;   // lv = -ln(loss_weight + 1e-6) as fp32, w = exp(-lv)
     int select_mode;
     int num_levels;
+    int walk_nb;             // joints with a branching subtree (SmplHostImage::walk_nb)
 };
 
 // LDS state of one player.  Float offsets of the arrays the level sweeps address by precomputed lane offsets:
 struct alignas(16) FitShared {
     alignas(16) float W[25 * 12];      // world transforms, 3x4 row-major [R | t]; slot 24 unused
     alignas(16) float Abar[25 * 12];   // reverse-sweep adjoints, 3x4 row-major [Bbar | abar]; slot 24 = zeros (absent child)
-    alignas(16) float Mt[24 * 16];     // forward operand: Mt[k][c] = column c of [[R_k, Jrel_k], [0, 1]]  (4 floats each)
+    alignas(16) float Mt[25 * 16];     // (slot 24 = identity: padding of the walks)  forward operand: Mt[k][c] = column c of [[R_k, Jrel_k], [0, 1]]  (4 floats each)
     alignas(16) float Tt[25 * 16];     // reverse operand: Tt[k][c] = (row c of R_k, Jrel_k[c]) for c < 3, (0,0,0,1) for c = 3
     alignas(16) float part[256];
     alignas(16) float part2[256];
@@ -108,6 +116,8 @@ struct alignas(16) FitShared {
     float tgt_px[34];
     float best_l2e;
     int take_best;
+    alignas(16) float Afin[26 * 12];   // reverse WALK: the total adjoints (Abar keeps the direct ones); slot 24 = zeros, 25 = spare
+    uint32_t childw[25];               // children of joint k, 5 bits each, 24 = none (SmplHostImage::walk[288 + k])
 };
 
 // Per-lane registers that live across iterations: Adam moments of parameter `lane`, this lane's ROLE in the
@@ -116,24 +126,27 @@ struct alignas(16) FitShared {
 struct FitLane {
     float m, v;
     int trainable;
-    // forward chain, per level: offsets (in floats, relative to FitShared) or -1 when idle
-    short cw[kMaxLevels];        // output element W[k][e]
-    short cwp[kMaxLevels];       // parent row W[p][i][0]
-    short cm[kMaxLevels];        // Mt[k][c][0]
-    // reverse sweep, per level: own element and, per child slot, the child's row / T-column operands
-    short ra[kMaxLevels];        // Abar[p][i][c]  (-1: idle)
-    short rrow[kMaxLevels][3];   // Abar[ch][i][0]          (absent child: zero slot 24)
-    short rt[kMaxLevels][3];     // Tt[ch][c][0]
-    short src17;                 // P6: source joint of fit joint `lane`
-    short wp216, wp72;           // P10: parent transform offsets
+    // Role in the level-synchronous sweeps, ONE word per level (lane = slot*12 + e handles element e of the slot-th joint of the
+    // level): bits 0-4 joint k, 5-9 its parent, 10-14 / 15-19 / 20-24 its children (24 = absent: the all-zero slot), bit 25 =
+    // takes part in the forward chain (k has a parent), bit 26 = takes part in the reverse sweep.  The LDS offsets are rebuilt
+    // from it with a handful of integer operations that do not depend on data (round 3: the 120 precomputed 16-bit offsets of
+    // rounds 1-2 cost 120 registers per lane -- 269 VGPRs; now 164-200, so a patch-convolution wave fits on the SIMD beside it).
+    uint32_t lvl[kMaxLevels];
+    uint32_t wlk[4];             // lanes 0..71: this lane's programs of the barrier-free tree walks (SmplHostImage::walk)
+    uint32_t eic;                // e | (4 i) << 8 | (4 c) << 16 with e = lane % 12 = 4 i + c
+    uint32_t role2;              // bits 0-9 / 10-19: P10 parent transform offsets (floats) of rotation entry / dJ entry `lane`;
+                                 // bits 20-24: P6 source joint of fit joint `lane`
     // loop-invariant model constants
-    float cJ[11];                // P1 lanes 0..143: bias + 10 shape coefficients of J / Jrel element
+    float cJ[11];                // P1 lanes 0..143: bias + 10 shape coefficients of J / Jrel element; lanes 240..254 (chunk 15 of the
+                                 //    face-vertex sums): template + 10 shape coefficients of coordinate lane & 15
     float cP[13];                // P1: posedirs coefficients of the face-vertex coordinate this lane accumulates
-    float cS[11];                // P1 chunk 15: template + 10 shape coefficients
     float cQ[15];                // P10: posedirs row of this lane's rotation entry
     float cC[6];                 // P11: d(beta) coefficients
-    float w2[2], w5[5], w3[3];   // LBS weights of the face vertices used in P4 / P7
+    float w2[2];                 // LBS weights of the face vertices used in P4
+    float w5[5];                 // ... in P7: lanes 64..135 five vertices of one joint, lanes 136..255 w5[0..2] = three joints of one vertex
 };
+
+constexpr uint32_t kLvlChain = 1u << 25, kLvlReverse = 1u << 26;
 
 #define SPSP_OFF(member) ((int)(offsetof(FitShared, member) / sizeof(float)))
 
@@ -149,7 +162,11 @@ SPSP_HD float* fit_f(FitShared& s) { return reinterpret_cast<float*>(&s); }
 SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, const int* parents,
                       const int* level_joints, const int* level_start, const int* child_start,
                       const int* child_list, const float* R, const float* betas, const float* cam,
-                      const float* joints2d, uint32_t param_mask) {
+                      const float* joints2d, uint32_t param_mask, const uint32_t* walk = nullptr) {
+    SPSP_UNROLL
+    for (int j = 0; j < 4; ++j) r.wlk[j] = walk ? walk[(lane >> 2) * 4 + j] : 0xffffffffu;
+    if (walk && lane < 25) s.childw[lane] = walk[256 + lane];
+    for (int i = lane; i < 26 * 12; i += kFitLanes) s.Afin[i] = 0.f;
     if (lane < 232) {
         const int p = lane;
         float v = 0.f;
@@ -169,45 +186,36 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
     for (int i = lane; i < 25 * 12; i += kFitLanes) { s.Abar[i] = 0.f; s.W[i] = 0.f; }
     for (int i = lane; i < 25 * 16; i += kFitLanes) {       // static parts: row 3 of Mt columns, Tt[.][3] = (0,0,0,1)
         const int c = (i >> 2) & 3, m = i & 3;
-        s.Tt[i] = (c == 3 && m == 3) ? 1.f : 0.f;
-        if (i < 24 * 16) s.Mt[i] = (c == 3 && m == 3) ? 1.f : 0.f;
+        s.Tt[i] = ((c == 3 || i >= 24 * 16) && m == c) ? 1.f : 0.f;       // (slot 24 of both: the identity)
+        s.Mt[i] = ((c == 3 || i >= 24 * 16) && m == c) ? 1.f : 0.f;
     }
     r.m = r.v = 0.f;
     r.trainable = lane < kNumPrm ? (int)fit_trainable(param_mask, lane) : 0;
 
     // ---- roles of this lane in the level sweeps (lane = slot*12 + e, e = i*4 + c) ----
     const int slot = lane / 12, e = lane % 12, i = e >> 2, c = e & 3;
+    r.eic = (uint32_t)e | ((uint32_t)(i * 4) << 8) | ((uint32_t)(c * 4) << 16);
     SPSP_UNROLL
     for (int l = 0; l < kMaxLevels; ++l) {
-        r.cw[l] = r.cwp[l] = r.cm[l] = r.ra[l] = -1;
-        SPSP_UNROLL
-        for (int n = 0; n < 3; ++n) { r.rrow[l][n] = (short)(SPSP_OFF(Abar) + 24 * 12); r.rt[l][n] = (short)(SPSP_OFF(Tt) + 24 * 16); }
+        uint32_t q = 0;
         const int idx = level_start[l < 25 ? l : 25] + slot;
         if (l < 25 && slot < 5 && idx < level_start[l + 1]) {
             const int k = level_joints[idx];
             const int p = parents[k];
-            if (p >= 0) {
-                r.cw[l] = (short)(SPSP_OFF(W) + k * 12 + e);
-                r.cwp[l] = (short)(SPSP_OFF(W) + p * 12 + i * 4);
-                r.cm[l] = (short)(SPSP_OFF(Mt) + k * 16 + c * 4);
-            }
-            r.ra[l] = (short)(SPSP_OFF(Abar) + k * 12 + e);
+            q = (uint32_t)k | kLvlReverse;
+            if (p >= 0) q |= ((uint32_t)p << 5) | kLvlChain;
             const int c0 = child_start[k], nc = child_start[k + 1] - c0;
             SPSP_UNROLL
-            for (int n = 0; n < 3; ++n)
-                if (n < nc) {
-                    const int ch = child_list[c0 + n];
-                    r.rrow[l][n] = (short)(SPSP_OFF(Abar) + ch * 12 + i * 4);
-                    r.rt[l][n] = (short)(SPSP_OFF(Tt) + ch * 16 + c * 4);
-                }
+            for (int n = 0; n < 3; ++n) q |= (uint32_t)(n < nc ? child_list[c0 + n] : 24) << (10 + 5 * n);
         }
+        r.lvl[l] = q;
     }
     {
         const int src_tab[17] = SPSP_FIT_SRC;
-        r.src17 = (short)(lane < 17 ? src_tab[lane] : 0);
+        const uint32_t wp216 = lane < 216 && lane >= 9 ? SPSP_OFF(W) + parents[lane / 9] * 12 : SPSP_OFF(W);
+        const uint32_t wp72 = lane < 72 && lane >= 3 ? SPSP_OFF(W) + parents[lane / 3] * 12 : SPSP_OFF(W);
+        r.role2 = wp216 | (wp72 << 10) | ((uint32_t)(lane < 17 ? src_tab[lane] : 0) << 20);
     }
-    r.wp216 = (short)(lane < 216 && lane >= 9 ? SPSP_OFF(W) + parents[lane / 9] * 12 : SPSP_OFF(W));
-    r.wp72 = (short)(lane < 72 && lane >= 3 ? SPSP_OFF(W) + parents[lane / 3] * 12 : SPSP_OFF(W));
 
     // ---- loop-invariant constants (read from the global copy of the fit constants) ----
     SPSP_UNROLL
@@ -223,9 +231,11 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
         const int q = lane >> 4, cc = lane & 15;
         SPSP_UNROLL
         for (int t = 0; t < 13; ++t) r.cP[t] = cc < 15 ? fitc[kFcP5 + (q * 13 + t) * kF5Pitch + cc] : 0.f;
-        r.cS[0] = (q == 15 && cc < 15) ? fitc[kFcVt5 + cc] : 0.f;
-        SPSP_UNROLL
-        for (int t = 0; t < 10; ++t) r.cS[1 + t] = (q == 15 && cc < 15) ? fitc[kFcS5 + t * kF5Pitch + cc] : 0.f;
+        if (q == 15 && cc < 15) {       // (lanes 240..254: not among the J lanes 0..143)
+            r.cJ[0] = fitc[kFcVt5 + cc];
+            SPSP_UNROLL
+            for (int t = 0; t < 10; ++t) r.cJ[1 + t] = fitc[kFcS5 + t * kF5Pitch + cc];
+        }
         SPSP_UNROLL
         for (int t = 0; t < 6; ++t) r.cC[t] = cc < 10 ? fitc[kFcC + cc * kCPitch + q * 6 + t] : 0.f;
         // P4: lane = q*16 + (v*3+i), joints 2q, 2q+1
@@ -237,10 +247,10 @@ SPSP_HD void fit_init(FitShared& s, FitLane& r, int lane, const float* fitc, con
     for (int t = 0; t < 15; ++t) r.cQ[t] = (lane >= 9 && lane < 216) ? fitc[kFcP5 + (lane - 9) * kF5Pitch + t] : 0.f;
     SPSP_UNROLL
     for (int v = 0; v < 5; ++v) r.w5[v] = (lane >= 64 && lane < 136) ? fitc[kFcW5 + v * 24 + (lane - 64) / 3] : 0.f;
-    {
-        const int idx = lane >= 136 ? lane - 136 : 0, q = idx / 15, o = idx % 15, v = o / 3;
+    if (lane >= 136) {
+        const int idx = lane - 136, q = idx / 15, o = idx % 15, v = o / 3;
         SPSP_UNROLL
-        for (int t = 0; t < 3; ++t) r.w3[t] = lane >= 136 ? fitc[kFcW5 + v * 24 + q * 3 + t] : 0.f;
+        for (int t = 0; t < 3; ++t) r.w5[t] = fitc[kFcW5 + v * 24 + q * 3 + t];
     }
 }
 
@@ -261,9 +271,12 @@ SPSP_HD void fit_p1(FitShared& s, const FitLane& r, int lane) {
         if (lane < 72) s.J[lane] = acc; else s.Jrel[lane - 72] = acc;
     }
     const int q = lane >> 4;
-    float acc = r.cS[0];
-    SPSP_UNROLL
-    for (int i = 0; i < 10; ++i) acc = fmaf(r.cS[1 + i], b[i], acc);
+    float acc = 0.f;
+    if (lane >= 240) {
+        acc = r.cJ[0];
+        SPSP_UNROLL
+        for (int i = 0; i < 10; ++i) acc = fmaf(r.cJ[1 + i], b[i], acc);
+    }
     const float* Rv = s.prm + kPrmR + 9 + q * 13;
     SPSP_UNROLL
     for (int t = 0; t < 13; ++t) acc = fmaf(r.cP[t], Rv[t], acc);
@@ -299,12 +312,171 @@ SPSP_HD void fit_p2(FitShared& s, int lane) {
 
 // P3[l]: kinematic chain, level l >= 1, in homogeneous form: W_k = W_p * [[R_k, Jrel_k], [0, 1]];
 //        element (i,c) = <row i of W_p (4), column c of the operand (4)>: two ds_read_b128 + 4 FMA.
-SPSP_HD void fit_chain_level(FitShared& s, const FitLane& r, int l) {
-    const int ow = r.cw[l];
-    if (ow < 0) return;
-    float* f = fit_f(s);
-    f[ow] = dot4(ld4(f + r.cwp[l]), ld4(f + r.cm[l]), 0.f);
+SPSP_HD void fit_chain_level(FitShared& s, const FitLane& r, uint32_t q) {      // q = the lane's role word of the level (FitLane::lvl)
+    SPSP_OPAQUE(q);
+    if (!(q & kLvlChain)) return;
+    const int k = q & 31, p = (q >> 5) & 31, e = r.eic & 255, i4 = (r.eic >> 8) & 255, c4 = (r.eic >> 16) & 255;
+    s.W[k * 12 + e] = dot4(ld4(s.W + p * 12 + i4), ld4(s.Mt + k * 16 + c4), 0.f);
 }
+
+// P3 as a WALK (round 3).  A quad of lanes carries ONE ROW of a world transform (lane & 3 = column) from the root down the path
+// to a leaf: W_k[i][c] = <row i of W_parent, column c of [[R_k, Jrel_k], [0, 1]]> with the row's four entries fetched from the
+// quad's lanes by DPP quad_perm -- no LDS hand-off between the tree levels, whose eight dependent round trips (~240 cycles
+// each) were the chain's cost; the operands (Mt, P2) are all there when the walk starts.  Every joint on the way is stored (the
+// rows shared by several leaves more than once, with the same value).  Same operations in the same order as the level sweep:
+// bit-identical (tests/emul runs both).  Paths are padded with joint 24 = the identity (Mt[24]; W[24] takes the stores).
+#if defined(__HIPCC__)
+template <int M>
+__device__ __forceinline__ float fit_quad_bcast(float v) {      // the value lane (lane & ~3) + M of this quad holds
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), M * 0x55, 0xf, 0xf, false));
+}
+#define SPSP_QDOT(v, T, init) fmaf(fit_quad_bcast<3>(v), (T).w, fmaf(fit_quad_bcast<2>(v), (T).z, fmaf(fit_quad_bcast<1>(v), (T).y, fmaf(fit_quad_bcast<0>(v), (T).x, init))))
+__device__ __forceinline__ void fit_chain_walk(FitShared& s, const FitLane& r, int lane) {
+    uint32_t lo = r.wlk[0], hi = r.wlk[1];
+    SPSP_OPAQUE(lo);
+    SPSP_OPAQUE(hi);
+    if ((lo & 31u) == 31u) return;                           // idle quad
+    const int i = (lane >> 2) % 3, c = lane & 3;
+    float v = s.W[i * 4 + c];                                // the root's row (P2)
+    int a[8];
+    F4 m[8];                                                 // all eight operands first: nothing below waits for LDS again
+    SPSP_UNROLL
+    for (int j = 0; j < 8; ++j) {
+        a[j] = (int)((j < 6 ? lo >> (5 * j) : hi >> (5 * (j - 6))) & 31u);
+        m[j] = ld4(s.Mt + a[j] * 16 + c * 4);
+    }
+    SPSP_UNROLL
+    for (int j = 0; j < 8; ++j) {
+        v = SPSP_QDOT(v, m[j], 0.f);
+        s.W[a[j] * 12 + i * 4 + c] = v;
+    }
+}
+
+// P9 as two WALKS.  Abar (P7) keeps the DIRECT adjoints, the totals go to Afin.
+//   a: quad 3 f + i starts with row i of leaf f's adjoint and climbs while the subtree is a path:
+//      row <- direct row of the parent + row x [[R_c^T, 0], [Jrel_c^T, 1]]  (the single-child case of the level sweep).
+//   b: quads 0..2 climb from the deepest joint with a BRANCHING subtree to the root -- in the SMPL tree 9, 6, 3, 0 with the
+//      children (12, 13, 14), (9), (6), (1, 2, 3): the structure is compiled in (kWalkB / kWalkBChildren; a model with another
+//      tree keeps the level sweeps, smpl_host.hpp), so every operand that does not come out of the walk itself is fetched up
+//      front.  At every joint the children are taken in the level sweep's order, the one just left from registers, the others
+//      (finished in a; same wavefront, LDS is in order) from Afin.  Same operations in the same order as the level sweep.
+__device__ __forceinline__ void fit_reverse_walk_a(FitShared& s, const FitLane& r, int lane) {
+    uint32_t p = r.wlk[2];
+    SPSP_OPAQUE(p);
+    if ((p & 31u) == 31u) return;
+    const int i = (lane >> 2) % 3, c = lane & 3;
+    int d = (int)(p & 31u);
+    float v = s.Abar[d * 12 + i * 4 + c];
+    int e[6];
+    float dir[6];
+    F4 T[6];
+    SPSP_UNROLL
+    for (int j = 1; j < 6; ++j) {
+        e[j] = (int)((p >> (5 * j)) & 31u);                  // 24 = padding: zero direct row, identity operand, store to the spare slot
+        dir[j] = s.Abar[e[j] * 12 + i * 4 + c];
+        T[j] = ld4(s.Tt + (e[j] == 24 ? 24 : d) * 16 + c * 4);
+        d = e[j] == 24 ? d : e[j];
+    }
+    s.Afin[(int)(p & 31u) * 12 + i * 4 + c] = v;
+    SPSP_UNROLL
+    for (int j = 1; j < 6; ++j) {
+        v = SPSP_QDOT(v, T[j], dir[j]);
+        s.Afin[(e[j] == 24 ? 25 : e[j]) * 12 + i * 4 + c] = v;
+    }
+}
+
+__device__ __forceinline__ void fit_reverse_walk_b(FitShared& s, const FitLane& r, int lane) {
+    uint32_t p = r.wlk[3];
+    SPSP_OPAQUE(p);
+    if ((p & 31u) == 31u) return;
+    const int i = (lane >> 2) % 3, c = lane & 3;
+    float dir[kWalkNB];
+    F4 T[kWalkNB][3], fin[kWalkNB][3];
+    SPSP_UNROLL
+    for (int j = 0; j < kWalkNB; ++j) {
+        dir[j] = s.Abar[kWalkB[j] * 12 + i * 4 + c];
+        SPSP_UNROLL
+        for (int n = 0; n < 3; ++n) {
+            const int ch = kWalkBChildren[j][n];
+            if (ch == 24) continue;
+            T[j][n] = ld4(s.Tt + ch * 16 + c * 4);
+            if (j == 0 || ch != kWalkB[j - 1]) fin[j][n] = ld4(s.Afin + ch * 12 + i * 4);
+        }
+    }
+    float prev = 0.f;
+    SPSP_UNROLL
+    for (int j = 0; j < kWalkNB; ++j) {
+        float acc = dir[j];
+        SPSP_UNROLL
+        for (int n = 0; n < 3; ++n) {
+            const int ch = kWalkBChildren[j][n];
+            if (ch == 24) continue;                          // (the level sweep multiplies a zero row here)
+            if (j > 0 && ch == kWalkB[j - 1]) acc = SPSP_QDOT(prev, T[j][n], acc);
+            else acc = dot4(fin[j][n], T[j][n], acc);
+        }
+        s.Afin[kWalkB[j] * 12 + i * 4 + c] = acc;
+        prev = acc;
+    }
+}
+#undef SPSP_QDOT
+#endif
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host twins (tests/emul): the same walks, a quad at a time
+inline void fit_chain_walk_host(FitShared& s, const uint32_t* walk) {
+    for (int q = 0; q < 64; ++q) {
+        const uint32_t lo = walk[q * 4], hi = walk[q * 4 + 1];
+        if ((lo & 31u) == 31u) continue;
+        const int i = q % 3;
+        F4 row = ld4(s.W + i * 4);
+        for (int j = 0; j < 8; ++j) {
+            const int a = (int)((j < 6 ? lo >> (5 * j) : hi >> (5 * (j - 6))) & 31u);
+            const float* M = s.Mt + a * 16;
+            row = F4{dot4(row, ld4(M), 0.f), dot4(row, ld4(M + 4), 0.f), dot4(row, ld4(M + 8), 0.f), dot4(row, ld4(M + 12), 0.f)};
+            st4(s.W + a * 12 + i * 4, row.x, row.y, row.z, row.w);
+        }
+    }
+}
+inline void fit_reverse_walk_host(FitShared& s, const uint32_t* walk, int nb) {
+    for (int q = 0; q < 64; ++q) {
+        const uint32_t p = walk[q * 4 + 2];
+        if ((p & 31u) == 31u) continue;
+        const int i = q % 3;
+        int d = (int)(p & 31u);
+        F4 v = ld4(s.Abar + d * 12 + i * 4);
+        st4(s.Afin + d * 12 + i * 4, v.x, v.y, v.z, v.w);
+        for (int j = 1; j < 6; ++j) {
+            const int e = (int)((p >> (5 * j)) & 31u);
+            const F4 dir = ld4(s.Abar + e * 12 + i * 4);
+            const float* T = s.Tt + (e == 24 ? 24 : d) * 16;
+            v = F4{dot4(v, ld4(T), dir.x), dot4(v, ld4(T + 4), dir.y), dot4(v, ld4(T + 8), dir.z), dot4(v, ld4(T + 12), dir.w)};
+            st4(s.Afin + (e == 24 ? 25 : e) * 12 + i * 4, v.x, v.y, v.z, v.w);
+            d = e == 24 ? d : e;
+        }
+    }
+    for (int q = 0; q < 3; ++q) {
+        const uint32_t p = walk[q * 4 + 3];
+        if ((p & 31u) == 31u) continue;
+        const int i = q % 3;
+        F4 prev = F4{0.f, 0.f, 0.f, 0.f};
+        int pb = 31;
+        for (int j = 0; j < nb; ++j) {
+            const int b = (int)((p >> (5 * j)) & 31u);
+            F4 acc = ld4(s.Abar + b * 12 + i * 4);
+            const uint32_t cw = s.childw[b];
+            for (int n = 0; n < 3; ++n) {
+                const int ch = (int)((cw >> (5 * n)) & 31u);
+                if (ch == 24) continue;
+                const F4 row = ch == pb ? prev : ld4(s.Afin + ch * 12 + i * 4);
+                const float* T = s.Tt + ch * 16;
+                acc = F4{dot4(row, ld4(T), acc.x), dot4(row, ld4(T + 4), acc.y), dot4(row, ld4(T + 8), acc.z), dot4(row, ld4(T + 12), acc.w)};
+            }
+            st4(s.Afin + b * 12 + i * 4, acc.x, acc.y, acc.z, acc.w);
+            prev = acc;
+            pb = b;
+        }
+    }
+}
+#endif
 
 // P4: face vertices x_v = sum_k w_vk (Rw_k (vp_v - J_k) + tw_k); lane = q*16 + (v*3+i), q < 12 = pair of joints.
 SPSP_HD void fit_p4(FitShared& s, const FitLane& r, int lane) {
@@ -336,13 +508,28 @@ SPSP_HD void fit_p5(FitShared& s, int lane) {
 // P6: project the 17 fit joints, residuals, per-joint loss / l2e / camera-gradient partials, dL/dX.
 //     pixels = (s (X + t) + 1) * img_wh/2  (cam_utils.py:5-26, joints2d_utils.py:5-10);
 //     n = 2 px / loss_wh - 1 on both sides, L = mean(d^2) * w + lv  (multi_task_loss.py:97-113).
-SPSP_HD void fit_p6(FitShared& s, const FitLane& r, int lane, const FitParams& P) {
+// from_partials: the face-vertex coordinates are summed here from P4's partials (P5's sum, same order) -- one LDS hand-off less.
+SPSP_HD void fit_p6(FitShared& s, const FitLane& r, int lane, const FitParams& P, bool from_partials = false) {
     if (lane >= 17) return;
-    const int src = r.src17;
+    uint32_t role2 = r.role2;
+    SPSP_OPAQUE(role2);
+    const int src = (role2 >> 20) & 31;
     float X[2];
     if (src < 24) { X[0] = s.W[src * 12 + 3]; X[1] = s.W[src * 12 + 7]; }
-    else { X[0] = s.xf[(src - 24) * 3]; X[1] = s.xf[(src - 24) * 3 + 1]; }
+    else if (from_partials) {
+        SPSP_UNROLL
+        for (int c = 0; c < 2; ++c) {
+            const float* p = s.part + ((src - 24) * 3 + c) * 16;
+            const F4 a = ld4(p), b = ld4(p + 4), cc = ld4(p + 8);
+            X[c] = ((a.x + a.y) + (a.z + a.w)) + (((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w)));
+        }
+    } else { X[0] = s.xf[(src - 24) * 3]; X[1] = s.xf[(src - 24) * 3 + 1]; }
     const float sc = s.prm[0];
+    // x / 2^k = x * 2^-k exactly: one multiplication in place of the division sequence (loss_wh = 256 in every reference fit)
+    uint32_t lw_bits;
+    memcpy(&lw_bits, &P.loss_wh, 4);
+    const bool lw_pow2 = (lw_bits & 0x807fffffu) == 0 && lw_bits >= 0x20000000u && lw_bits <= 0x5f000000u;
+    const float lw_inv = 1.0f / P.loss_wh;
     const float half = P.img_wh / 2.0f;
     const float dn_du = (2.0f * half) / P.loss_wh;           // d n / d u
     const float coef = (2.0f * P.weight) / 34.0f;            // d L / d n = coef * (n - n*)
@@ -353,8 +540,9 @@ SPSP_HD void fit_p6(FitShared& s, const FitLane& r, int lane, const FitParams& P
         const float u = sc * (X[c] + t);
         const float px = (u + 1.f) * half;
         const float y = s.tgt_px[lane * 2 + c];
-        const float n = (2.0f * px) / P.loss_wh - 1.0f;
-        const float ns = (2.0f * y) / P.loss_wh - 1.0f;
+        float n, ns;
+        if (lw_pow2) { n = (2.0f * px) * lw_inv - 1.0f; ns = (2.0f * y) * lw_inv - 1.0f; }
+        else { n = (2.0f * px) / P.loss_wh - 1.0f; ns = (2.0f * y) / P.loss_wh - 1.0f; }
         const float d = n - ns;
         loss = fmaf(d, d, loss);
         const float dp = px - y;
@@ -409,7 +597,7 @@ SPSP_HD void fit_p7(FitShared& s, const FitLane& r, int lane) {
         SPSP_UNROLL
         for (int t = 0; t < 3; ++t) {
             const int k = q * 3 + t;
-            acc = fmaf(r.w3[t], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
+            acc = fmaf(r.w5[t], fmaf(s.W[k * 12 + l], h0, s.W[k * 12 + 4 + l] * h1), acc);
         }
         s.part2[o * 16 + q] = acc;
     }
@@ -438,27 +626,33 @@ SPSP_HD void fit_p8(FitShared& s, int lane, const FitParams& P, int it, float* l
 //   Abar_p += sum over children ch of  Abar_ch * [[R_ch^T, 0], [Jrel_ch^T, 1]]
 //   element (i,c) += <row i of Abar_ch (4), Tt[ch][c] (4)>: two ds_read_b128 + 4 FMA per child.
 //   Absent children point at the all-zero slot 24 of Abar.
-SPSP_HD void fit_reverse_level(FitShared& s, const FitLane& r, int l) {
-    const int oa = r.ra[l];
-    if (oa < 0) return;
-    float* f = fit_f(s);
-    float acc = f[oa];
+SPSP_HD void fit_reverse_level(FitShared& s, const FitLane& r, uint32_t q) {
+    SPSP_OPAQUE(q);
+    if (!(q & kLvlReverse)) return;
+    const int k = q & 31, e = r.eic & 255, i4 = (r.eic >> 8) & 255, c4 = (r.eic >> 16) & 255;
+    float acc = s.Abar[k * 12 + e];
     SPSP_UNROLL
-    for (int n = 0; n < 3; ++n) acc = dot4(ld4(f + r.rrow[l][n]), ld4(f + r.rt[l][n]), acc);
-    f[oa] = acc;
+    for (int n = 0; n < 3; ++n) {
+        const int ch = (q >> (10 + 5 * n)) & 31;
+        acc = dot4(ld4(s.Abar + ch * 12 + i4), ld4(s.Tt + ch * 16 + c4), acc);
+    }
+    s.Abar[k * 12 + e] = acc;
 }
 
 // P10: rotation gradients incl. the pose-blend-shape path through the face vertices (lanes 0..215) and the
 //      total dJ (lanes 0..71, after their rotation item).
-SPSP_HD void fit_p10(FitShared& s, const FitLane& r, int lane) {
+SPSP_HD void fit_p10(FitShared& s, const FitLane& r, int lane, bool walked = false) {
+    const float* const AB = walked ? s.Afin : s.Abar;        // where the reverse pass left the total adjoints
     float* f = fit_f(s);
+    uint32_t role2 = r.role2;
+    SPSP_OPAQUE(role2);
     if (lane < 216) {                                        // item (k, l, c): dR_k[l][c]
         const int k = lane / 9, e = lane % 9, l = e / 3, c = e % 3;
         float acc;
-        if (k == 0) acc = s.Abar[l * 4 + c];
+        if (k == 0) acc = AB[l * 4 + c];
         else {
-            const float* Wp = f + r.wp216;
-            const float* A = s.Abar + k * 12 + c;
+            const float* Wp = f + (role2 & 1023);
+            const float* A = AB + k * 12 + c;
             acc = Wp[l] * A[0];
             acc = fmaf(Wp[4 + l], A[4], acc);
             acc = fmaf(Wp[8 + l], A[8], acc);
@@ -471,11 +665,11 @@ SPSP_HD void fit_p10(FitShared& s, const FitLane& r, int lane) {
     }
     if (lane < 72) {                                         // dJ_total[k][l]
         const int k = lane / 3, l = lane % 3;
-        const float* A = s.Abar + k * 12 + 3;                // abar_k[i] = A[4 i]
+        const float* A = AB + k * 12 + 3;                // abar_k[i] = A[4 i]
         float acc = s.dJ[lane];
         if (k == 0) acc += A[4 * l];
         else {
-            const float* Wp = f + r.wp72;
+            const float* Wp = f + ((role2 >> 10) & 1023);
             acc = fmaf(Wp[l], A[0], fmaf(Wp[4 + l], A[4], fmaf(Wp[8 + l], A[8], acc)));
         }
         const float* Wk = s.W + k * 12;

@@ -60,14 +60,14 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_multiview_kernel(const Mv
 #define MV_FORWARD()                                                                         \
     fit_p1(s, r, lane); __syncthreads();                                                     \
     fit_p2(s, lane); __syncthreads();                                                        \
-    for (int l = 1; l < L; ++l) { fit_chain_level(s, r, l); __syncthreads(); }               \
+    for (int l = 1; l < L; ++l) { fit_chain_level(s, r, r.lvl[l]); __syncthreads(); }               \
     fit_p4(s, r, lane); __syncthreads();                                                     \
     fit_p5(s, lane); __syncthreads();                                                        \
     fit_p6(s, r, lane, P); __syncthreads();                                                  \
     fit_p7(s, r, lane); __syncthreads();
 #define MV_BACKWARD()                                                                        \
     fit_p8(s, lane, P, 0, nullptr, nullptr); __syncthreads();                                \
-    for (int l = L - 2; l >= 0; --l) { fit_reverse_level(s, r, l); __syncthreads(); }        \
+    for (int l = L - 2; l >= 0; --l) { fit_reverse_level(s, r, r.lvl[l]); __syncthreads(); }        \
     fit_p10(s, r, lane); __syncthreads();                                                    \
     fit_p11(s, r, lane); __syncthreads();
 

@@ -300,6 +300,7 @@ struct spsp_regressor {
     int patch_tile[4];     // per residual stage: output pixels per patch-kernel tile (256: 8 waves, 128: 4 waves)
     int patch_ring[4];     // per residual stage: depth of the patch kernel's weight ring, in groups of three slabs (2 or 3)
     int patch_nch[4];      // per residual stage: output channels per patch-kernel workgroup (64; 32 = twice the workgroups, layer4)
+    bool patch_prod[4];    // per residual stage: four producer waves issue the patch kernel's LDS-DMA (128-pixel tiles only)
     unsigned int* err_host = nullptr;   // pinned, mapped, coherent host word: device-side failures of this handle's kernels (bit 0: IEF hand-off time-out)
     unsigned int* err_dev = nullptr;    // the same word as the kernels see it
     int ief_capacity = 0;               // IEF workgroups the device can hold at once (occupancy x CUs)
@@ -342,7 +343,8 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
         ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
-        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], r->patch_nch[L], st);
+        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], r->patch_nch[L],
+                                 r->patch_prod[L] && r->patch_tile[L] == 128 && r->patch_ring[L] == 3 && r->patch_db[L], st);
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
@@ -486,7 +488,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // tools/ab_pipeline.py: 116.0 k vs 113.4 k players/s); a single batch in flight finishes sooner on 256 workgroups
         // (18.9 -> 13.2 us per launch, tools/ab_plan.py): spsp_regressor_set_plan(SPSP_PLAN_LATENCY)
         const int def_nch[4] = {64, 64, 64, 64};
-        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; }
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; r->patch_prod[L] = false; }
 #if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
         if (const char* e = getenv("SPSP_PATCH_RING")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_ring[0], &r->patch_ring[1], &r->patch_ring[2], &r->patch_ring[3]);
@@ -645,6 +647,12 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             const int L = value / 10000, tile = (value % 10000) / 10, ring = (value % 10) / 2, db = value & 1;
             SPSP_REQUIRE(L >= 1 && L <= 3 && (tile == 128 || tile == 256) && (ring == 2 || ring == 3), "spsp_regressor_debug: patch plan %d", value);
             r->patch_tile[L] = tile; r->patch_ring[L] = ring; r->patch_db[L] = db != 0;
+            return SPSP_OK;
+        }
+        case SPSP_DEBUG_PLAN_PATCH_PRODUCER: {      // value = layer * 10 + (0 | 1)
+            const int L = value / 10;
+            SPSP_REQUIRE(L >= 1 && L <= 3 && value % 10 <= 1, "spsp_regressor_debug: producer plan %d", value);
+            r->patch_prod[L] = value % 10 != 0;
             return SPSP_OK;
         }
         default: break;

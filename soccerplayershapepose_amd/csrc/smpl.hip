@@ -161,14 +161,16 @@ __global__ __launch_bounds__(256) void smpl_extra_joints_kernel(const float* __r
                                                                 const int* __restrict__ csr_col,
                                                                 const float* __restrict__ csr_val,
                                                                 float* __restrict__ joints) {
+    // grid (players, 12): ONE regressor row per wavefront (round 3; one workgroup per player walked its 45 rows four at a time,
+    // 20 us of dependent gathers for 32 players -- part of the serial tail every pipeline slot waits for)
     const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* vb = verts + (size_t)b * kV3;
     float* jb = joints + (size_t)b * SPSP_NUM_OUT_JOINTS * 3;
-    if (threadIdx.x < 63) {
+    if (blockIdx.y == 0 && threadIdx.x < 63) {
         int j = threadIdx.x / 3, c = threadIdx.x % 3;
         jb[(24 + j) * 3 + c] = vb[pick_ids[j] * 3 + c];
     }
-    for (int r = wave; r < 45; r += 4) {
+    for (int r = blockIdx.y * 4 + wave; r < 45; r += 48) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int e = csr_ptr[r] + lane; e < csr_ptr[r + 1]; e += 64) {
             const float w = csr_val[e];
@@ -214,6 +216,9 @@ int spsp_smpl_load(spsp_ctx* ctx, const spsp_smpl_arrays* a, int max_batch, spsp
     TRY(s->pool.upload(&s->d_level_start, h.level_start, (size_t)26));
     TRY(s->pool.upload(&s->child_start, h.child_start, (size_t)25));
     TRY(s->pool.upload(&s->child_list, h.child_list, (size_t)24));
+    TRY(s->pool.upload(&s->walk, h.walk, (size_t)(64 * 4 + 25)));
+    s->walk_ok = h.walk_ok;
+    s->walk_nb = h.walk_nb;
     TRY(s->pool.upload(&s->pick_ids, a->vertex_joint_ids, (size_t)21));
     TRY(s->pool.upload(&s->csr_ptr, h.csr_ptr.data(), h.csr_ptr.size()));
     TRY(s->pool.upload(&s->csr_col, h.csr_col.data(), h.csr_col.size()));
@@ -258,7 +263,7 @@ int smpl_forward_impl(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
     SPSP_HIP_CHECK(hipGetLastError());
     if (joints) {
         ProfScope ps(ctx, kKSmplJoints, st, true);
-        launch_kernel(&smpl_extra_joints_kernel, dim3(B), dim3(256), 0, st, v, s->pick_ids, s->csr_ptr, s->csr_col, s->csr_val, joints);
+        launch_kernel(&smpl_extra_joints_kernel, dim3(B, 12), dim3(256), 0, st, v, s->pick_ids, s->csr_ptr, s->csr_col, s->csr_val, joints);
         SPSP_HIP_CHECK(hipGetLastError());
     }
     return SPSP_OK;

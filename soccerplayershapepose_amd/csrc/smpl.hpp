@@ -20,6 +20,9 @@ struct spsp_smpl {
     int* d_level_start;  // device copy [26]
     int* child_start;    // [25] children of joint k: child_list[child_start[k] .. child_start[k+1])
     int* child_list;     // [24] (23 used)
+    uint32_t* walk;      // [64 * 4 + 25] programs of the fit's tree walks (SmplHostImage::walk)
+    bool walk_ok;
+    int walk_nb;
     int* pick_ids;       // [21]
     int* csr_ptr;        // [46] extra-joint regressors (9 + 19 + 17 rows) in CSR
     int* csr_col;

@@ -29,4 +29,10 @@ constexpr int kFcC = kFcW5 + 120;                         // [10][97]   d(beta) 
 constexpr int kFcJrel = kFcC + 10 * kCPitch;              // [72 + 10*73]  same as Jbar/JS for J_k - J_parent(k) (root: J_0)
 constexpr int kFcTotal = kFcJrel + 72 + 10 * kJSPitch;    // 6416 floats = 25.7 KB
 
+// The kinematic tree the walks are compiled for: SMPL's (every SMPL / SMPL-family body model file carries this parents array).
+constexpr int kSmplParents[24] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+constexpr int kWalkNB = 4;                                   // joints with a branching subtree, deepest first, and their children
+constexpr int kWalkB[kWalkNB] = {9, 6, 3, 0};
+constexpr int kWalkBChildren[kWalkNB][3] = {{12, 13, 14}, {9, 24, 24}, {6, 24, 24}, {1, 2, 3}};
+
 }  // namespace spsp

@@ -21,6 +21,17 @@ struct SmplHostImage {
     int child_start[25];
     int child_list[24];
     int face_ids[kNFace];
+    // Programs of the fit's tree WALKS (fit_core.hpp: fit_chain_walk, fit_reverse_walk_a / _b).  A walk is carried by QUADS of
+    // lanes (quad = lane >> 2 holds one matrix row, lane & 3 its column); quad 3 f + i walks row i along leaf f's path.  Four
+    // words per quad, then one word of children per joint (+ the padding joint 24):
+    //   [0], [1]  the joints from below the root down to the leaf, 5 bits each (6 in the first word), padded with 24
+    //   [2]       the leaf, then its ancestors as long as their subtree is a path, 5 bits each, padded with 24
+    //   [3]       quads 0..2: the joints with a BRANCHING subtree from the deepest one up to the root, 5 bits each, padded with 24
+    //   an idle quad / program has 31 in its first field
+    //   walk[256 + k] = the three children of k, 5 bits each, 24 = none
+    uint32_t walk[64 * 4 + 25];
+    int walk_nb;             // joints with a branching subtree
+    bool walk_ok;            // the tree fits that scheme (SMPL's does): joints with a branching subtree form one path from the root
 };
 
 // Returns an empty string on success, else the reason.
@@ -88,7 +99,7 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
             maxd = std::max(maxd, depth[k]);
         }
         h.num_levels = maxd + 1;
-        if (h.num_levels > 12) return "kinematic tree deeper than 12 levels (fit kernel limit; SMPL has 9)";
+        if (h.num_levels > 9) return "kinematic tree deeper than 9 levels (fit kernel limit; SMPL has 9)";
         for (int k = 0; k < kNJ; ++k) {
             int nc = 0;
             for (int c = 1; c < kNJ; ++c) nc += a.parents[c] == k;
@@ -111,6 +122,60 @@ inline std::string smpl_prepare(const spsp_smpl_arrays& a, SmplHostImage& h, boo
                 if (a.parents[c] == k) h.child_list[n++] = c;
         }
         h.child_start[24] = n;
+        // walk programs
+        int nch[kNJ], onlych[kNJ];
+        bool is_path[kNJ];
+        for (int k = 0; k < kNJ; ++k) { nch[k] = h.child_start[k + 1] - h.child_start[k]; onlych[k] = nch[k] ? h.child_list[h.child_start[k]] : -1; }
+        for (int l = maxd; l >= 0; --l)
+            for (int k = 0; k < kNJ; ++k)
+                if (depth[k] == l) is_path[k] = nch[k] == 0 || (nch[k] == 1 && is_path[onlych[k]]);
+        h.walk_ok = maxd <= 8;
+        std::vector<int> bjoints, leaves;               // branching joints root first; leaves
+        for (int cur = is_path[0] ? -1 : 0; cur >= 0;) {
+            bjoints.push_back(cur);
+            int nb = 0, next = -1;
+            for (int c = h.child_start[cur]; c < h.child_start[cur + 1]; ++c)
+                if (!is_path[h.child_list[c]]) { ++nb; next = h.child_list[c]; }
+            if (nb > 1) h.walk_ok = false;
+            cur = nb == 1 ? next : -1;
+        }
+        for (int k = 0; k < kNJ; ++k)
+            if (nch[k] == 0) leaves.push_back(k);
+        if (bjoints.size() > 6 || leaves.size() > 5) h.walk_ok = false;     // (<= 5 leaves: the 15 quads of a walk share wavefront 0)
+        h.walk_nb = (int)bjoints.size();
+        for (int k = 1; k < kNJ; ++k)
+            if (a.parents[k] != kSmplParents[k]) h.walk_ok = false;      // the reverse walk's upper part is compiled for SMPL's tree (fit_core.hpp)
+        for (int q = 0; q < 64 * 4; ++q) h.walk[q] = 0xffffffffu;
+        auto put = [](uint32_t* w, const std::vector<int>& v, size_t first_word_fields) {
+            uint32_t a0 = 0, a1 = 0;
+            for (size_t j = 0; j < first_word_fields; ++j) a0 |= (uint32_t)(j < v.size() ? v[j] : 24) << (5 * j);
+            for (size_t j = first_word_fields; j < first_word_fields + 2; ++j) a1 |= (uint32_t)(j < v.size() ? v[j] : 24) << (5 * (j - first_word_fields));
+            w[0] = a0; w[1] = a1;
+        };
+        for (size_t f = 0; f < leaves.size() && f < 5; ++f) {
+            std::vector<int> down, up;
+            for (int j = leaves[f]; j > 0; j = a.parents[j]) down.insert(down.begin(), j);
+            for (int j = leaves[f]; j >= 0 && is_path[j]; j = j ? a.parents[j] : -1) up.push_back(j);
+            if (down.size() > 8 || up.size() > 6) h.walk_ok = false;
+            for (int i = 0; i < 3; ++i) {
+                uint32_t* w = h.walk + (3 * f + i) * 4;
+                uint32_t tmp[2];
+                put(w, down, 6);
+                put(tmp, up, 6);
+                w[2] = tmp[0];
+            }
+        }
+        if (!bjoints.empty()) {
+            std::vector<int> bup(bjoints.rbegin(), bjoints.rend());
+            uint32_t tmp[2];
+            put(tmp, bup, 6);
+            for (int i = 0; i < 3; ++i) h.walk[i * 4 + 3] = tmp[0];
+        }
+        for (int k = 0; k <= kNJ; ++k) {
+            uint32_t cw = 0;
+            for (int n3 = 0; n3 < 3; ++n3) cw |= (uint32_t)(k < kNJ && n3 < nch[k] ? h.child_list[h.child_start[k] + n3] : 24) << (5 * n3);
+            h.walk[256 + k] = cw;
+        }
     }
     // fit constants (face vertices = first 5 picked ids: nose, reye, leye, rear, lear)
     h.fitc.assign(kFcTotal, 0.f);

@@ -118,13 +118,13 @@ __global__ __launch_bounds__(spsp::kFitLanes) void smpl_vjp_kernel(const float* 
     __syncthreads();
     fit_p1(s, r, lane); __syncthreads();
     fit_p2(s, lane); __syncthreads();
-    for (int l = 1; l < L; ++l) { fit_chain_level(s, r, l); __syncthreads(); }
+    for (int l = 1; l < L; ++l) { fit_chain_level(s, r, r.lvl[l]); __syncthreads(); }
     // no joints2D loss: its seeds (ga, h) stay zero, so P7 leaves zero adjoints for the dense seeds to add to
     fit_p7(s, r, lane); __syncthreads();
     if (lane < 15) { s.dvp[lane] = 0.f; s.adj[lane] = 0.f; }
     fit_dense_inject(s, lane, seeds + (size_t)b * 288);
     __syncthreads();
-    for (int l = L - 2; l >= 0; --l) { fit_reverse_level(s, r, l); __syncthreads(); }
+    for (int l = L - 2; l >= 0; --l) { fit_reverse_level(s, r, r.lvl[l]); __syncthreads(); }
     fit_p10(s, r, lane); __syncthreads();
     fit_p11(s, r, lane); __syncthreads();
     if (lane < 216) grad_R[(size_t)b * 216 + lane] = s.grad[kPrmR + lane] + (lane >= 9 ? gcoef[(size_t)b * kNCoef + kNB + (lane - 9)] : 0.f);

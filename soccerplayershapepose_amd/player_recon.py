@@ -7,6 +7,7 @@ Mirrors (same names, argument meaning, in-place contract):
 The reference runs these one player at a time with a full SMPL.forward + autograd per iteration; here a
 whole batch of players is ONE kernel launch (csrc/fit.hip), one wavefront per player."""
 import ctypes as C
+import os
 from types import SimpleNamespace
 
 import torch
@@ -474,6 +475,7 @@ class PlayerPipeline:
             self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
                                               smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False, pending=[]))
         self._next = 0
+        self._nudge_in, self._nudge_keep = None, None
 
     def submit(self, proxy_rep, joints2D, **kw):
         """Issue one batch on the next slot.  With `use_graphs` the slot's ~60 launches are captured once into a
@@ -484,6 +486,7 @@ class PlayerPipeline:
         self._next = (self._next + 1) % len(self.slots)
         caller = torch.cuda.current_stream(self.device)
         slot.stream.wait_stream(caller)                                     # inputs produced on the caller's stream
+        self._nudge(caller)
         for ev in slot.pending:                                             # readers of the slot's previous results on other streams
             slot.stream.wait_event(ev)                                      # (res.hold_until): the slot's buffers are about to be rewritten
         slot.pending.clear()
@@ -502,6 +505,31 @@ class PlayerPipeline:
         res.stream = slot.stream
         res.hold_until = slot.pending.append
         return _with_wait(res)
+
+    def _nudge(self, caller):
+        """One trivial kernel (a 64-float fill) on the caller's stream, `2 * depth` submits after the last graph capture.
+        Measured in round 3 (tools/pipe_probe6.py, pipe_probe9.py recipes R1-R8, bench.py --probe; always the same box and the
+        same process otherwise, results bit-identical): the graph-replay pipeline has TWO speeds, 108-110 k and 122-128 k
+        players/s.  It runs at the lower one as long as no kernel has been launched on the stream the slots synchronise with
+        (`wait_stream(caller)`) since the graphs started replaying -- a loop that only submits and synchronises, as bench.py
+        and the probes do -- and switches to the higher one when such a launch arrives while every slot has at most one replay
+        outstanding (any kernel does: this fill, one of the library's own, a result consumer; an allocation or an idle second
+        does not; neither does any runtime switch of libamdhip64 -- GPU_MAX_HW_QUEUES, HIP_FORCE_DEV_KERNARG,
+        DEBUG_CLR_GRAPH_PACKET_CAPTURE, DEBUG_HIP_DYNAMIC_QUEUES ...: tools/.. run g3ao).  The lower speed equals the one with
+        DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, so the likely reading is that the replays then take the runtime's node-by-node path;
+        we cannot see into the runtime from here.  An application that consumes its results on its stream is in the fast
+        state anyway.  SPSP_PIPE_NO_NUDGE=1 switches the fill off, SPSP_PIPE_NUDGE_PERIOD=n repeats it every n submits (A/B)."""
+        if self._nudge_in is None or os.environ.get('SPSP_PIPE_NO_NUDGE'):
+            return
+        self._nudge_in -= 1
+        if self._nudge_in <= 0:
+            with torch.cuda.stream(caller):
+                if self._nudge_keep is None:
+                    self._nudge_keep = torch.zeros(64, dtype=torch.float32, device=self.device)
+                else:
+                    self._nudge_keep.zero_()
+            period = int(os.environ.get('SPSP_PIPE_NUDGE_PERIOD', '0'))
+            self._nudge_in = period if period > 0 else None
 
     def _submit_graph(self, slot, proxy_rep, joints2D, kw):
         if not (torch.is_tensor(proxy_rep) and proxy_rep.is_cuda and torch.is_tensor(joints2D) and joints2D.is_cuda):
@@ -522,6 +550,7 @@ class PlayerPipeline:
                     slot.graphs.pop(next(iter(slot.graphs)))
                 # the inputs are kept alive with the graph that reads them
                 entry = slot.graphs[key] = (g, res, proxy_rep, joints2D)
+                self._nudge_in = 2 * len(self.slots)
             g, res = entry[0], entry[1]
             slot.regressor.check_status()        # a replay makes no library call: device-side failures of earlier batches surface here
             g.replay()

@@ -36,7 +36,7 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
         FitLane r[kFitLanes];
         float* Rb = R + (size_t)b * 216; float* bb = betas + (size_t)b * 10; float* cb = cam + (size_t)b * 3;
         ALL_LANES(fit_init(s, r[lane], lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb,
-                           cb, joints2d + (size_t)b * 34, param_mask));
+                           cb, joints2d + (size_t)b * 34, param_mask, h.walk_ok ? h.walk : nullptr));
         float* lh = loss_hist ? loss_hist + (size_t)b * iters : nullptr;
         float* eh = l2e_hist ? l2e_hist + (size_t)b * iters : nullptr;
         double b1t = 1.0, b2t = 1.0;
@@ -47,14 +47,29 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
             const float bc2_sqrt = (float)std::sqrt(1.0 - b2t);
             ALL_LANES(fit_p1(s, r[lane], lane));
             ALL_LANES(fit_p2(s, lane));
-            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], l)); }
+            // the product kernel walks the tree (fit_chain_walk / fit_reverse_walk_*); the level sweeps it replaced run beside it
+            // here on a copy of the state, and the two must agree BIT FOR BIT (same operations in the same order)
+            FitShared lv = s;
+            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(lv, r[lane], r[lane].lvl[l])); }
+            if (h.walk_ok) {
+                fit_chain_walk_host(s, h.walk);
+                if (std::memcmp(s.W, lv.W, sizeof(float) * 24 * 12) != 0) return -2;
+            } else s = lv;
             ALL_LANES(fit_p4(s, r[lane], lane));
-            ALL_LANES(fit_p5(s, lane));
-            ALL_LANES(fit_p6(s, r[lane], lane, P));
+            ALL_LANES(fit_p6(s, r[lane], lane, P, true));      // (P5 folded in, as in fit.hip)
             ALL_LANES(fit_p7(s, r[lane], lane));
             ALL_LANES(fit_p8(s, lane, P, it, lh, eh));
-            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], l)); }
-            ALL_LANES(fit_p10(s, r[lane], lane));
+            if (h.walk_ok) {
+                lv = s;
+                for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(lv, r[lane], r[lane].lvl[l])); }
+                fit_reverse_walk_host(s, h.walk, h.walk_nb);
+                for (int i = 0; i < 24 * 12; ++i)
+                    if (!(s.Afin[i] == lv.Abar[i])) return -3;          // (== : +0 and -0 agree)
+                ALL_LANES(fit_p10(s, r[lane], lane, true));
+            } else {
+                for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], r[lane].lvl[l])); }
+                ALL_LANES(fit_p10(s, r[lane], lane));
+            }
             ALL_LANES(fit_p11(s, r[lane], lane));
             if (it == 0 && grad_first) {      // gradient of the first iteration, record order [cam|R|betas]
                 float* g = grad_first + (size_t)b * kNumPrm;

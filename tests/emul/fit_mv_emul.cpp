@@ -52,7 +52,7 @@ extern "C" int fit_mv_emulate(const spsp_smpl_arrays* model, int iters, int roun
         auto forward = [&]() {
             ALL_LANES(fit_p1(s, r[lane], lane));
             ALL_LANES(fit_p2(s, lane));
-            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], l)); }
+            for (int l = 1; l < L; ++l) { ALL_LANES(fit_chain_level(s, r[lane], r[lane].lvl[l])); }
             ALL_LANES(fit_p4(s, r[lane], lane));
             ALL_LANES(fit_p5(s, lane));
             ALL_LANES(fit_p6(s, r[lane], lane, P));
@@ -60,7 +60,7 @@ extern "C" int fit_mv_emulate(const spsp_smpl_arrays* model, int iters, int roun
         };
         auto backward = [&]() {
             ALL_LANES(fit_p8(s, lane, P, 0, nullptr, nullptr));
-            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], l)); }
+            for (int l = L - 2; l >= 0; --l) { ALL_LANES(fit_reverse_level(s, r[lane], r[lane].lvl[l])); }
             ALL_LANES(fit_p10(s, r[lane], lane));
             ALL_LANES(fit_p11(s, r[lane], lane));
         };

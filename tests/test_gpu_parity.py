@@ -243,6 +243,64 @@ def test_fit_is_deterministic_and_batch_independent(smpl_gpu, dev):
     assert torch.equal(Rg[0], runs[0][0][5]) and torch.equal(cg[0], runs[0][2][5])
 
 
+def test_patch_kernels_with_producer_waves_are_bit_identical(dev):
+    """csrc/conv_patch.hip, PROD: four DMA-only wavefronts per workgroup issue the LDS-DMA pieces in place of the accumulating
+    waves (layer3 / layer4, 128-pixel tiles; `SPSP_DEBUG_PLAN_PATCH_PRODUCER`).  The arithmetic is untouched, so every output of
+    the regressor and the layer3 / layer4 feature maps must equal the plain kernels' bit for bit -- both precisions, both layer4
+    block widths, B = 32 (full grid) and B = 6 (ragged last tiles)."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec in ('f16', 'bf16'):
+        for B in (32, 6):
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=40 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            for nch in (64, 32):
+                got = []
+                for prod in (0, 1):
+                    r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_LAYER4_CHANNELS, nch), 'debug')
+                    for L in (2, 3):
+                        r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + prod), 'debug')
+                    out = [t.clone() for t in reg(native)]
+                    out += [reg.read_stage(st, B).clone() for st in (4, 5)]
+                    torch.cuda.synchronize()
+                    reg.check_status()
+                    got.append(out)
+                for a, b in zip(*got):
+                    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, monkeypatch):
+    """The fit's kinematic chain and reverse sweep run as register-resident walks over quads of lanes (csrc/fit_core.hpp:
+    fit_chain_walk, fit_reverse_walk_a / _b -- DPP row broadcasts in place of eight LDS hand-offs per sweep); the level sweeps
+    they replaced remain for models with another tree and are selected by SPSP_FIT_LEVEL_SWEEPS (read at every launch).  Same
+    operations in the same order: every iterate of both variants, all 229 parameters of 7 players over 50 iterations, bit for bit."""
+    from soccerplayershapepose_amd.player_recon import fit_players
+    B = 7
+    R, b, cam = S.pose_params(B, seed=77, body_deg=25, global_deg=40)
+    out = smpl_gpu(body_pose=torch.from_numpy(R[:, 1:]).to(dev), global_orient=torch.from_numpy(R[:, :1]).to(dev), betas=torch.from_numpy(b).to(dev))
+    tgt = S.fit_targets_from_joints(out.joints.cpu().numpy(), cam * np.array([1.1, 1, 1], np.float32), seed=5)
+    runs = []
+    for sweeps in (False, True):
+        if sweeps:
+            monkeypatch.setenv('SPSP_FIT_LEVEL_SWEEPS', '1')
+        else:
+            monkeypatch.delenv('SPSP_FIT_LEVEL_SWEEPS', raising=False)
+        for variant in (0, 1):
+            Rg, bg, cg = (torch.from_numpy(a).to(dev).contiguous() for a in (R, b, cam))
+            hist = fit_players(smpl_gpu, Rg, bg, cg, tgt, variant=variant, iters=50, return_trajectory=True)
+            torch.cuda.synchronize()
+            runs.append([Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist])
+    monkeypatch.delenv('SPSP_FIT_LEVEL_SWEEPS', raising=False)
+    for walk, level in ((runs[0], runs[2]), (runs[1], runs[3])):
+        assert len(walk) == len(level) == 6
+        for x, y in zip(walk, level):
+            assert torch.equal(x, y)
+    assert not torch.equal(runs[1][0], torch.from_numpy(R).to(dev))         # (the fit did move the pose)
+
+
 # ---------------------------------------------------------------- silhouette term and the reference's exact best-iterate rule (8f-4, a11)
 def test_silhouette_render_and_metric_against_restated_neural_renderer(smpl_gpu, smpl_model_np, dev):
     """csrc/silhouette.hip vs oracle/silhouette.py (neural_renderer's projection + silhouette rasterisation restated):

@@ -28,13 +28,13 @@ def patch(L, tile, ring, db):
     return (_abi.DEBUG_PLAN_PATCH, L * 10000 + tile * 10 + ring * 2 + db)
 
 
+prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in layers]
 PLANS = {
-    'round2 (ring s2, layer4 64ch)': [(_abi.DEBUG_PLAN_S2, 0), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
     's2 + layer4 64ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
+    's2 + layer4 64ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)] + prod(2, 3),
+    's2 + layer4 64ch + producer waves in layer3': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)] + prod(2),
+    's2 + layer4 32ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)] + prod(2, 3),
     's2 + layer4 32ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)],
-    's2 + 64ch + small-LDS patch kernels (128 px, ring 2, one patch: 2 per CU)':
-        [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 2, 0), patch(2, 128, 2, 0), patch(3, 128, 2, 0)],
-    's2 + 64ch + layer2 as 128 px, ring 3, one patch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 3, 0)],
 }
 streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
 x, _ = S.proxy_crops(B, seed=1234)

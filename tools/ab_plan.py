@@ -2,6 +2,7 @@
 profiling scopes, one batch in flight) and the whole forward, for every setting of
     stride-2 stages:  ring kernel of round 2 | parity-plane patch kernel (conv_s2.hip)
     layer4 3x3 convs: 64- | 32-channel blocks
+    layer3 / layer4:  with | without four DMA-only producer waves per workgroup
 usage: python tools/ab_plan.py [B] [reps]"""
 import ctypes as C
 import os
@@ -51,10 +52,12 @@ def whole():
 
 
 ref = None
-for s2 in (0, 1):
-    for nch in (64, 32):
+for s2, nch, prod in ((0, 64, 0), (1, 64, 0), (1, 32, 0), (1, 64, 1), (1, 32, 1)):
+    if True:
         r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2, s2), 'debug')
         r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_LAYER4_CHANNELS, nch), 'debug')
+        for L in (2, 3):       # layer3, layer4: four DMA-only producer waves in the 128-pixel patch kernels
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + prod), 'debug')
         out = reg(native)
         torch.cuda.synchronize()
         if ref is None:
@@ -62,5 +65,5 @@ for s2 in (0, 1):
         dev_ = max((a - b).abs().max().item() for a, b in zip(out, ref))
         k = profile()
         conv = sum(v[0] * v[1] for n, v in k.items() if n.startswith('conv'))
-        print(f's2={s2} layer4_channels={nch}: forward {whole():7.1f} us, conv kernels {conv:6.1f} us/forward, max |out - first setting| {dev_:.2e}')
+        print(f's2={s2} layer4_channels={nch} producer_waves={prod}: forward {whole():7.1f} us, conv kernels {conv:6.1f} us/forward, max |out - first setting| {dev_:.2e}')
         print('     ' + ', '.join(f'{n} {v[0]:.2f} x{v[1]:.0f}' for n, v in k.items() if n.startswith('conv')))
