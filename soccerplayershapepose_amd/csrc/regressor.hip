@@ -488,7 +488,11 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // tools/ab_pipeline.py: 116.0 k vs 113.4 k players/s); a single batch in flight finishes sooner on 256 workgroups
         // (18.9 -> 13.2 us per launch, tools/ab_plan.py): spsp_regressor_set_plan(SPSP_PLAN_LATENCY)
         const int def_nch[4] = {64, 64, 64, 64};
-        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; r->patch_prod[L] = false; }
+        // layer3 / layer4 (128-pixel tiles, four accumulating waves): four DMA-only producer waves per workgroup (conv_patch.hip,
+        // PROD) -- layer4's launch 18.2 -> 15.5 us (64-channel blocks), 13.0 -> 12.6 (32), layer3's 12.7 -> 12.1, bit-identical
+        // results (tools/ab_plan.py, run g3aa); in the four-slot pipeline the gain is within the noise (+0.4 %, tools/ab_pipeline.py)
+        const bool def_prod[4] = {false, false, true, true};
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; r->patch_prod[L] = def_prod[L] && !getenv("SPSP_NO_PATCH_PRODUCERS"); }
 #if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
         if (const char* e = getenv("SPSP_PATCH_RING")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_ring[0], &r->patch_ring[1], &r->patch_ring[2], &r->patch_ring[3]);

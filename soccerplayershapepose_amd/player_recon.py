@@ -485,10 +485,25 @@ class PlayerPipeline:
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         caller = torch.cuda.current_stream(self.device)
-        slot.stream.wait_stream(caller)                                     # inputs produced on the caller's stream
         self._nudge(caller)
+        # inputs produced on the caller's stream: the slot must not start before they are there
+        if self.use_graphs and not os.environ.get('SPSP_PIPE_EVENT_WAIT'):
+            # ... on the HOST when a graph is about to be replayed.  Round 3, ROCm 7.2: a replay issued behind
+            # hipStreamWaitEvent on a REAL event of another stream (one recorded behind a kernel; an event on an idle stream
+            # completes on the spot and the wait is dropped) ran 13 % "faster" and gave WRONG results -- vertices centimetres off
+            # while every run without such a wait is bit-identical to the serial path; an ordinary dispatch between the wait and
+            # the replay did not help.  bench.py's parity gate found it.  So no event wait precedes a replay:
+            # an idle caller stream (the common case) costs one hipStreamQuery, a busy one is waited for on the host; the same
+            # goes for the readers registered through `hold_until` above.  SPSP_PIPE_EVENT_WAIT=1 restores the event waits (A/B).
+            if not caller.query():
+                caller.synchronize()
+        else:
+            slot.stream.wait_stream(caller)
         for ev in slot.pending:                                             # readers of the slot's previous results on other streams
-            slot.stream.wait_event(ev)                                      # (res.hold_until): the slot's buffers are about to be rewritten
+            if self.use_graphs and not os.environ.get('SPSP_PIPE_EVENT_WAIT'):
+                ev.synchronize()                                            # (on the host in front of a graph replay: see below)
+            else:
+                slot.stream.wait_event(ev)                                  # (res.hold_until): the slot's buffers are about to be rewritten
         slot.pending.clear()
         # The inputs were allocated on the caller's stream and are read on the slot's: tell the caching allocator, or a
         # buffer the caller drops right after submit() is handed to the caller's next allocation while this batch still
@@ -507,19 +522,11 @@ class PlayerPipeline:
         return _with_wait(res)
 
     def _nudge(self, caller):
-        """One trivial kernel (a 64-float fill) on the caller's stream, `2 * depth` submits after the last graph capture.
-        Measured in round 3 (tools/pipe_probe6.py, pipe_probe9.py recipes R1-R8, bench.py --probe; always the same box and the
-        same process otherwise, results bit-identical): the graph-replay pipeline has TWO speeds, 108-110 k and 122-128 k
-        players/s.  It runs at the lower one as long as no kernel has been launched on the stream the slots synchronise with
-        (`wait_stream(caller)`) since the graphs started replaying -- a loop that only submits and synchronises, as bench.py
-        and the probes do -- and switches to the higher one when such a launch arrives while every slot has at most one replay
-        outstanding (any kernel does: this fill, one of the library's own, a result consumer; an allocation or an idle second
-        does not; neither does any runtime switch of libamdhip64 -- GPU_MAX_HW_QUEUES, HIP_FORCE_DEV_KERNARG,
-        DEBUG_CLR_GRAPH_PACKET_CAPTURE, DEBUG_HIP_DYNAMIC_QUEUES ...: tools/.. run g3ao).  The lower speed equals the one with
-        DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, so the likely reading is that the replays then take the runtime's node-by-node path;
-        we cannot see into the runtime from here.  An application that consumes its results on its stream is in the fast
-        state anyway.  SPSP_PIPE_NO_NUDGE=1 switches the fill off, SPSP_PIPE_NUDGE_PERIOD=n repeats it every n submits (A/B)."""
-        if self._nudge_in is None or os.environ.get('SPSP_PIPE_NO_NUDGE'):
+        """TEST HOOK (SPSP_PIPE_TEST_NUDGE=1): a 64-float fill on the caller's stream `2 * depth` submits after the last graph
+        capture, then every SPSP_PIPE_NUDGE_PERIOD submits -- the smallest stand-in for an application that runs kernels of
+        its own on the stream it submits from.  It is what exposed the hazard `submit()` now avoids (see there):
+        tests/test_gpu_parity.py::test_player_pipeline_is_correct_next_to_kernels_on_the_callers_stream."""
+        if self._nudge_in is None or not os.environ.get('SPSP_PIPE_TEST_NUDGE'):
             return
         self._nudge_in -= 1
         if self._nudge_in <= 0:
