@@ -310,7 +310,7 @@ def main():
         mk_s = lambda: SMPL(model, max_batch=B)
         return PlayerPipeline(mk_r, mk_s, dev, depth=max(1, args.depth), streams=streams)
 
-    pipe = make_pipe(args.precision, streams=[torch.cuda.Stream(device=dev) for _ in range(max(1, args.depth))] if os.environ.get('BENCH_UPFRONT_STREAMS') else None)
+    pipe = make_pipe(args.precision)
     reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl
     r = rt.get(dev)
     lanes = max(1, min(args.exchange_lanes, len(pipe.slots)))
