@@ -359,7 +359,10 @@ def main():
             k = state.i % len(natives_)
             state.i += 1
             inp = create_proxy_representation_batch(sil_dev, joints_dev, precision=precision) if args.from_detections else natives_[k]
-            res = pipe_.submit(inp, inputs[k].tgt, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+            # (N > 1: the record is read by the exchange on its own stream -- two alternating sets of result buffers per slot, so that
+            # a slot's next batch does not wait for the all-gather of its previous one)
+            bset = ((state.i - 1) // len(pipe_.slots)) & 1 if use_dist and lanes == 1 else 0
+            res = pipe_.submit(inp, inputs[k].tgt, buffer_set=bset, fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
             res.input_index = k
             if use_dist:
                 with torch.cuda.stream(res.stream):
@@ -428,7 +431,7 @@ def main():
             # each slot's step is captured into a HIP graph (untimed) and replayed; events are not recorded inside graphs
             pipe_.use_graphs = True
             import math
-            for _ in range(math.lcm(len(pipe_.slots), n_inputs)):      # every (slot, input batch) pair that will occur
+            for _ in range(math.lcm(len(pipe_.slots), n_inputs) * (2 if use_dist else 1)):      # every (slot, input batch[, buffer set]) that will occur
                 step_fn()
             torch.cuda.synchronize()
         # untimed: the W warm-up steps of the contract -- through the very path that is timed, with nothing but the barrier +

@@ -473,15 +473,18 @@ class PlayerPipeline:
         for i in range(depth):
             st = streams[i] if streams is not None else torch.cuda.Stream(device=self.device)
             self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
-                                              smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False, pending=[]))
+                                              smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False, pending={}))
         self._next = 0
         self._nudge_in, self._nudge_keep = None, None
 
-    def submit(self, proxy_rep, joints2D, **kw):
+    def submit(self, proxy_rep, joints2D, buffer_set=0, **kw):
         """Issue one batch on the next slot.  With `use_graphs` the slot's ~60 launches are captured once into a
         HIP graph (keyed by the input buffers and options) and replayed: ~20 us of host time per batch instead of
         ~180 us, bit-identical results; the returned tensors are then the graph's static outputs, valid until
-        the same slot is submitted to again (depth submits later)."""
+        the same slot is submitted to again (depth submits later).
+        `buffer_set` (graphs): a slot keeps one set of static result buffers per value -- a caller whose results are read by
+        work on ANOTHER stream (`res.hold_until(event)`: the record exchange of a multi-GPU run) alternates two sets, so that
+        the slot's next batch does not have to wait for the reader of the previous one (bench.py: 100.8 k -> see DESIGN 6)."""
         slot = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
         caller = torch.cuda.current_stream(self.device)
@@ -499,12 +502,13 @@ class PlayerPipeline:
                 caller.synchronize()
         else:
             slot.stream.wait_stream(caller)
-        for ev in slot.pending:                                             # readers of the slot's previous results on other streams
+        pending = slot.pending.setdefault(buffer_set if self.use_graphs else 0, [])
+        for ev in pending:                                                  # readers of this buffer set's previous results on other streams
             if self.use_graphs and not os.environ.get('SPSP_PIPE_EVENT_WAIT'):
-                ev.synchronize()                                            # (on the host in front of a graph replay: see below)
+                ev.synchronize()                                            # (on the host in front of a graph replay: see above)
             else:
                 slot.stream.wait_event(ev)                                  # (res.hold_until): the slot's buffers are about to be rewritten
-        slot.pending.clear()
+        pending.clear()
         # The inputs were allocated on the caller's stream and are read on the slot's: tell the caching allocator, or a
         # buffer the caller drops right after submit() is handed to the caller's next allocation while this batch still
         # reads it.  The results are allocated on the slot's stream: consume them on another stream through res.wait().
@@ -512,13 +516,13 @@ class PlayerPipeline:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(slot.stream)
         if self.use_graphs:
-            return self._submit_graph(slot, proxy_rep, joints2D, kw)
+            return self._submit_graph(slot, proxy_rep, joints2D, kw, buffer_set, pending)
         with torch.cuda.stream(slot.stream):
             res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
             res.done = torch.cuda.Event()
             res.done.record(slot.stream)
         res.stream = slot.stream
-        res.hold_until = slot.pending.append
+        res.hold_until = pending.append
         return _with_wait(res)
 
     def _nudge(self, caller):
@@ -538,11 +542,11 @@ class PlayerPipeline:
             period = int(os.environ.get('SPSP_PIPE_NUDGE_PERIOD', '0'))
             self._nudge_in = period if period > 0 else None
 
-    def _submit_graph(self, slot, proxy_rep, joints2D, kw):
+    def _submit_graph(self, slot, proxy_rep, joints2D, kw, buffer_set, pending):
         if not (torch.is_tensor(proxy_rep) and proxy_rep.is_cuda and torch.is_tensor(joints2D) and joints2D.is_cuda):
             raise ValueError('PlayerPipeline(use_graphs=True): inputs must be device tensors (a graph replays fixed buffers)')
         key = (proxy_rep.data_ptr(), tuple(proxy_rep.shape), proxy_rep.dtype, joints2D.data_ptr(), tuple(joints2D.shape),
-               joints2D.dtype, tuple(sorted(kw.items())))
+               joints2D.dtype, tuple(sorted(kw.items())), buffer_set)
         with torch.cuda.stream(slot.stream):
             entry = slot.graphs.get(key)
             if entry is None:
@@ -553,7 +557,7 @@ class PlayerPipeline:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=slot.stream):
                     res = reconstruct_players(slot.regressor, slot.smpl, proxy_rep, joints2D, **kw)
-                if len(slot.graphs) >= 8:
+                if len(slot.graphs) >= 16:
                     slot.graphs.pop(next(iter(slot.graphs)))
                 # the inputs are kept alive with the graph that reads them
                 entry = slot.graphs[key] = (g, res, proxy_rep, joints2D)
@@ -565,7 +569,7 @@ class PlayerPipeline:
             out.done = torch.cuda.Event()
             out.done.record(slot.stream)
         out.stream = slot.stream
-        out.hold_until = slot.pending.append
+        out.hold_until = pending.append
         return _with_wait(out)
 
     def synchronize(self):
