@@ -13,6 +13,17 @@ from soccerplayershapepose_amd import _abi, synthetic as S
 pytestmark = pytest.mark.gpu
 
 
+def _oracle_fit_vertices(oracle_smpl, R, betas, tgt, cam, iters=50):
+    """Vertices of the CPU oracle's pose+shape fit for a batch of players (oracle/fit.py:fit_pose_shape_batch -- the per-player
+    reference loop in one autograd graph, checked against that loop in tests/test_oracle_golden.py)."""
+    from oracle import fit as OF
+    r = OF.fit_pose_shape_batch(oracle_smpl, R[:, 1:], R[:, :1], betas, np.asarray(tgt), cam, iters=iters)
+    body, Gm, be, ca, _ = r['last']
+    with torch.no_grad():
+        return oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
+
+
+
 @pytest.fixture(scope='module')
 def dev():
     assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
@@ -861,14 +872,8 @@ def test_end_to_end_against_oracle_pipeline(regressor_gpu, regressor_gpu_f16, sm
     res = reconstruct_players(regressor_gpu, smpl_gpu, xt, tgt, fit='pose_shape', iters=50, return_vertices2d=True)
     assert res.vertices.shape == (B, 6890, 3) and res.vertices2d.shape == (B, 6890, 2)
     # (i) oracle fit + SMPL from the GPU regressor outputs
-    worst = 0.0
-    for i in range(B):
-        r = OF.fit_pose_shape(oracle_smpl, R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape0[i:i + 1].cpu(), tgt[i],
-                              cam0[i:i + 1].cpu(), iters=50)
-        body, Gm, be, ca, _ = r['last']
-        with torch.no_grad():
-            v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
-        worst = max(worst, (res.vertices[i].cpu() - v[0]).abs().max().item())
+    v = _oracle_fit_vertices(oracle_smpl, R0.cpu(), shape0.cpu(), tgt, cam0.cpu())
+    worst = (res.vertices.cpu() - v).abs().max().item()
     print(f'fit + SMPL kernels vs oracle fit + SMPL from identical regressor outputs ({precision}): {worst:.3e} m')
     assert worst < 1e-3, f'fit+SMPL kernels vs oracle from identical regressor outputs: {worst}'
     # (ii) everything fp32 on the CPU (the reference path end to end)
@@ -878,13 +883,8 @@ def test_end_to_end_against_oracle_pipeline(regressor_gpu, regressor_gpu_f16, sm
         pre_o = oracle_smpl(body_pose=R_o[:, 1:], global_orient=R_o[:, :1], betas=shape_o).vertices
     pre = smpl_gpu(full_pose=R0, betas=shape0).vertices.cpu()
     dev_pre = (pre - pre_o).abs().max().item()
-    per_player = []
-    for i in range(B):
-        r = OF.fit_pose_shape(oracle_smpl, R_o[i:i + 1, 1:], R_o[i:i + 1, :1], shape_o[i:i + 1], tgt[i], cam_o[i:i + 1], iters=50)
-        body, Gm, be, ca, _ = r['last']
-        with torch.no_grad():
-            v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
-        per_player.append((res.vertices[i].cpu() - v[0]).abs().max().item())
+    v = _oracle_fit_vertices(oracle_smpl, R_o, shape_o, tgt, cam_o)
+    per_player = (res.vertices.cpu() - v).abs().amax(dim=(1, 2)).tolist()
     print(f'{precision} backbone vs all-fp32 oracle, max vertex deviation: regressor -> SMPL {dev_pre:.3e} m; '
           f'after the 50-iteration fit per player {[f"{d:.2e}" for d in per_player]} m')
     # Backbone -> SMPL (no optimiser in between): the north-star 1e-3 m holds with fp16 storage (measured 9e-5);
@@ -922,13 +922,8 @@ def test_north_star_all_32_players_of_the_bench_batch_within_1e_3_m_of_the_fp32_
     with torch.no_grad():
         pre_o = oracle_smpl(body_pose=R_o[:, 1:], global_orient=R_o[:, :1], betas=shape_o).vertices
     pre_dev = (pre - pre_o).abs().amax(dim=(1, 2))
-    post_dev = []
-    for i in range(B):
-        r = OF.fit_pose_shape(oracle_smpl, R_o[i:i + 1, 1:], R_o[i:i + 1, :1], shape_o[i:i + 1], tgt[i], cam_o[i:i + 1], iters=50)
-        body, Gm, be, ca, _ = r['last']
-        with torch.no_grad():
-            v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
-        post_dev.append((res.vertices[i].cpu() - v[0]).abs().max().item())
+    v = _oracle_fit_vertices(oracle_smpl, R_o, shape_o, tgt, cam_o)
+    post_dev = (res.vertices.cpu() - v).abs().amax(dim=(1, 2)).tolist()
     print(f'north star, 32 players: pre-fit max {pre_dev.max().item():.3e} m, post-fit median {sorted(post_dev)[16]:.3e} max {max(post_dev):.3e} m')
     assert pre_dev.max().item() < 1e-3
     assert max(post_dev) < 1e-3, f'players beyond 1e-3 m after the fit: {[(i, d) for i, d in enumerate(post_dev) if d >= 1e-3]}'
@@ -979,13 +974,10 @@ def test_batch_256_every_block_of_32_is_bit_identical_and_a_sample_matches_the_o
         err, scale = (stages[si] - ost[n]).abs().max().item(), ost[n].abs().max().item()
         assert err <= 0.02 * 0.125 * scale, f'stage {n} at B = 256: max err {err} vs scale {scale}'
     # (iii) fit + SMPL kernels at B = 256 against the oracle, from the GPU's own regressor outputs
-    for i in sample:
-        r = OF.fit_pose_shape(oracle_smpl, R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape[i:i + 1].cpu(), tgt[i].cpu().numpy(),
-                              cam[i:i + 1].cpu(), iters=50)
-        body, Gm, be, ca, _ = r['last']
-        with torch.no_grad():
-            v = oracle_smpl(body_pose=body, global_orient=Gm, betas=be).vertices
-        assert (res.vertices[i].cpu() - v[0]).abs().max().item() < 1e-3, f'player {i} of 256'
+    idx = torch.tensor(list(sample))
+    v = _oracle_fit_vertices(oracle_smpl, R0.cpu()[idx], shape.cpu()[idx], tgt.cpu().numpy()[idx.numpy()], cam.cpu()[idx])
+    dev_s = (res.vertices.cpu()[idx] - v).abs().amax(dim=(1, 2))
+    assert dev_s.max().item() < 1e-3, f'players of 256 beyond 1e-3 m: {[(int(i), float(d)) for i, d in zip(idx, dev_s) if d >= 1e-3]}'
 
 
 def test_ief_hand_off_time_out_is_reported_as_an_error_not_as_silent_nans(regressor_sd_np, dev):
@@ -1240,7 +1232,7 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
     clip by the CPU oracle in two ways: TEACHER-FORCED (the oracle fit of a frame starts from the GPU's previous state: 2e-4 on
     raw parameters -- per-frame errors cannot hide behind each other; frames 0-3, 10, 20 and 29: all 30 passed in round 3, an
     oracle fit takes 2.4 s) and FREE-RUNNING (the oracle chains its own results from the same regressor outputs: 2e-4 per frame
-    over the first three frames, and for player 0 the final vertices after all 30 chained fits within the north-star 1e-3 m)."""
+    over the first three frames, and the final vertices after all 30 chained fits within the north-star 1e-3 m)."""
     from soccerplayershapepose_amd.player_recon import reconstruct_players, single_view_optimization
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
     from oracle import fit as OF, smpl as OS
@@ -1269,27 +1261,26 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
         if t > 0:
             rec = single_view_optimization(smpl_gpu, body, orient, betas, cam, targets[t], interation=50)
             body, orient, betas, cam = rec.body_pose, rec.global_orient, rec.betas, rec.cam_wp
-        for i in follow:
-            gpu_now = (body[i:i + 1].cpu(), orient[i:i + 1].cpu(), betas[i:i + 1].cpu(), cam[i:i + 1].cpu())
-            if t in (0, 1, 2, 3, 10, 20, 29):
-                ob, og, obe, oc, _ = OF.fit_pose_shape(oracle_smpl, *forced[i][:3], targets[t][i], forced[i][3], iters=50)['last']
-                d = max((gpu_now[0] - ob).abs().max().item(), (gpu_now[1] - og).abs().max().item(), (gpu_now[2] - obe).abs().max().item(),
-                        (gpu_now[3] - oc).abs().max().item())
-                worst_forced = max(worst_forced, d)
-                assert d < 2e-4, f'frame {t} player {i}: {d} from the oracle fit started at the same state'
-            forced[i] = gpu_now
-            if i != follow[0] and t >= 3:
-                continue                                     # the second player's free chain: the first three frames
-            fb, fg, fbe, fc, _ = OF.fit_pose_shape(oracle_smpl, *free[i][:3], targets[t][i], free[i][3], iters=50)['last']
-            free[i] = (fb.detach(), fg.detach(), fbe.detach(), fc.detach())
-            d = max((gpu_now[0] - fb).abs().max().item(), (gpu_now[1] - fg).abs().max().item(), (gpu_now[2] - fbe).abs().max().item(),
-                    (gpu_now[3] - fc).abs().max().item())
-            worst_free = max(worst_free, d)
-            if t < 3:
-                assert d < 2e-4, f'frame {t} player {i}: {d} from the free-running oracle chain'
+        fl = list(follow)
+        gpu_now = (body[fl].cpu(), orient[fl].cpu(), betas[fl].cpu(), cam[fl].cpu())
+        tg = np.stack([targets[t][i] for i in fl])
+        cat = lambda d, k: torch.cat([d[i][k] for i in fl])
+        if t in (0, 1, 2, 3, 10, 20, 29):        # (both followed players in one batched oracle fit: oracle/fit.py:fit_pose_shape_batch)
+            o = OF.fit_pose_shape_batch(oracle_smpl, cat(forced, 0), cat(forced, 1), cat(forced, 2), tg, cat(forced, 3), iters=50)['last']
+            d = max((gpu_now[k] - o[k]).abs().max().item() for k in range(4))
+            worst_forced = max(worst_forced, d)
+            assert d < 2e-4, f'frame {t}: {d} from the oracle fit started at the same state'
+        f = OF.fit_pose_shape_batch(oracle_smpl, cat(free, 0), cat(free, 1), cat(free, 2), tg, cat(free, 3), iters=50)['last']
+        d = max((gpu_now[k] - f[k]).abs().max().item() for k in range(4))
+        worst_free = max(worst_free, d)
+        if t < 3:
+            assert d < 2e-4, f'frame {t}: {d} from the free-running oracle chain'
+        for n, i in enumerate(fl):
+            forced[i] = tuple(g[n:n + 1] for g in gpu_now)
+            free[i] = tuple(f[k][n:n + 1].detach() for k in range(4))
     out = smpl_gpu(body_pose=body, global_orient=orient, betas=betas)
     vdev = 0.0
-    for i in follow[:1]:
+    for i in follow:
         with torch.no_grad():
             v = oracle_smpl(body_pose=free[i][0], global_orient=free[i][1], betas=free[i][2]).vertices[0]
         vdev = max(vdev, (out.vertices[i].cpu() - v).abs().max().item())
