@@ -1,5 +1,5 @@
 """Correctness of the four-slot graph pipeline under load: every 7th result of a 200-step run (and the last four) against the serial
-eager path on the same inputs, bit for bit.  usage: python tools/pipe_check.py [prod0|prod1] (nudge: SPSP_PIPE_NO_NUDGE)"""
+eager path on the same inputs, bit for bit.  usage: python tools/pipe_check.py [prod0|prod1] [eager] [soak]   (SPSP_PIPE_TEST_NUDGE=1 SPSP_PIPE_NUDGE_PERIOD=n: fills on the caller's stream)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +12,7 @@ from soccerplayershapepose_amd.models.smpl_official import SMPL
 from soccerplayershapepose_amd.player_recon import PlayerPipeline, reconstruct_players
 prod = 0 if 'prod0' in sys.argv else 1
 B, steps = 32, 200
+rounds = 12 if 'soak' in sys.argv else 5
 dev = torch.device('cuda', 0)
 r = rt.get(dev)
 sd, model = S.regressor_state_dict(seed=0), S.smpl_model(seed=0)
@@ -21,7 +22,7 @@ def mk_r():
         r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + prod), 'debug')
     return reg
 mk_s = lambda: SMPL(model, max_batch=B)
-pipe = PlayerPipeline(mk_r, mk_s, dev, depth=4, use_graphs=True)
+pipe = PlayerPipeline(mk_r, mk_s, dev, depth=4, use_graphs='eager' not in sys.argv)
 inputs, refs = [], []
 ref_reg, ref_smpl = mk_r(), mk_s().to(dev)
 for k in range(4):
@@ -32,7 +33,7 @@ for k in range(4):
     torch.cuda.synchronize()
     inputs.append((nat, tgt))
     refs.append((ref.vertices.clone(), ref.cam.clone(), ref.rotmats.clone()))
-for rd in range(5):
+for rd in range(rounds):
     last = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
