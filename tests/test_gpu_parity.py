@@ -1081,7 +1081,7 @@ def test_player_pipeline_is_correct_next_to_kernels_on_the_callers_stream(dev, m
         torch.cuda.synchronize()
         inputs.append((nat, tgt))
         refs.append((ref.vertices.clone(), ref.cam.clone(), ref.rotmats.clone()))
-    pipe = PlayerPipeline(mk_r, mk_s, dev, depth=4, use_graphs=True)
+    pipe = PlayerPipeline(mk_r, mk_s, dev, depth=4, use_graphs=not os.environ.get('TEST_PIPE_EAGER'))
     # bench.py's sequence, the one that went wrong: four capturing submits, five warm-up submits, a synchronisation, then the
     # loop -- the hook's first fill lands on its third submit (2 x depth submits after the last capture), while every slot has
     # at most one replay outstanding; with SPSP_PIPE_EVENT_WAIT=1 (the event waits of rounds 1-2) this test fails on ROCm 7.2
