@@ -35,6 +35,7 @@ PLANS = {
     's2 + layer4 64ch + producer waves in layer3': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)] + prod(2),
     's2 + layer4 32ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)] + prod(2, 3),
     's2 + layer4 32ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)],
+    's2 + 64ch + producers in layer3 / layer4 + layer2 as 128 px tiles with producers': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 3, 1)] + prod(1, 2, 3),
 }
 streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
 x, _ = S.proxy_crops(B, seed=1234)

@@ -52,12 +52,14 @@ def whole():
 
 
 ref = None
-for s2, nch, prod in ((0, 64, 0), (1, 64, 0), (1, 32, 0), (1, 64, 1), (1, 32, 1)):
+for s2, nch, prod in ((1, 64, 0), (1, 64, 1), (1, 64, 2), (1, 32, 1)):      # prod 2: also layer2, as 128-pixel tiles
     if True:
         r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2, s2), 'debug')
         r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_LAYER4_CHANNELS, nch), 'debug')
         for L in (2, 3):       # layer3, layer4: four DMA-only producer waves in the 128-pixel patch kernels
-            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + prod), 'debug')
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + (1 if prod else 0)), 'debug')
+        r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH, 1 * 10000 + (128 if prod == 2 else 256) * 10 + 3 * 2 + (1 if prod == 2 else 0)), 'debug')
+        r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_PATCH_PRODUCER, 10 + (1 if prod == 2 else 0)), 'debug')
         out = reg(native)
         torch.cuda.synchronize()
         if ref is None:
