@@ -503,19 +503,28 @@ def main():
     flo, fhi = shard_range(FRAME_PLAYERS, world, rank)
     fn = fhi - flo
     reg.set_plan('latency')        # one batch in flight: layer4 on the whole chip (include/spsp.h, SPSP_PLAN_LATENCY)
+    pipe.use_graphs = bool(args.graphs)
     lat = []
     for i in range(25):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if fn > 0:
-            fres = reconstruct_players(reg, smpl, native[:fn], tgt[:fn], fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+            # through slot 0 of the pipeline: with HIP graphs (the default) the frame's ~35 launches are ONE graph replay (captured
+            # in the first of the 5 untimed repetitions, with the latency plan) -- the launch gaps of the eager chain are ~0.07 ms
+            if args.graphs:
+                pipe._next = 0
+                fres = pipe.submit(native[:fn], tgt[:fn], fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
+            else:
+                fres = reconstruct_players(reg, smpl, native[:fn], tgt[:fn], fit=args.fit, iters=FIT_ITERS, return_record=use_dist)
         if use_dist:
-            rec = fres.record if fn > 0 else torch.zeros((0, 229), dtype=torch.float32, device=dev)
-            exchange.all_gather(rec, FRAME_PLAYERS)
+            with torch.cuda.stream(pipe.slots[0].stream if args.graphs else torch.cuda.current_stream(dev)):
+                rec = fres.record if fn > 0 else torch.zeros((0, 229), dtype=torch.float32, device=dev)
+                exchange.all_gather(rec, FRAME_PLAYERS)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t0)
     reg.set_plan('throughput')
+    pipe._next = 0
     lat_t = torch.tensor(sorted(lat[5:])[len(lat[5:]) // 2], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(lat_t, op=dist.ReduceOp.MAX)
@@ -584,7 +593,7 @@ def main():
                          'end_to_end_backbone_tflops': FLOP_BACKBONE * world * B * args.steps / elapsed / 1e12,
                          'end_to_end_backbone_frac': FLOP_BACKBONE * B * args.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS},
             'latency': {'workload': f'one {FRAME_PLAYERS}-player match frame (BASELINE configs[3]) through the whole path, nothing else in '
-                                    f'flight (regressor plan "latency"), {world} GPU(s)' + (', players sharded 3,3,... + all-gather' if world > 1 else ''),
+                                    f'flight (regressor plan "latency"' + (', one HIP-graph replay' if args.graphs else '') + f'), {world} GPU(s)' + (', players sharded 3,3,... + all-gather' if world > 1 else ''),
                         'ms': frame_latency_ms},
             'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},
