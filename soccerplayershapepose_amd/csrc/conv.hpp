@@ -56,6 +56,11 @@ int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels = 64
 bool conv_s2_supported(const ConvArgs& a);
 int launch_conv_s2(const ConvArgs& a, hipStream_t stream);
 
+// conv_s2rs.hip: layer2.0's 3x3 / 2 + 1x1 / 2 pair (one 64-channel chunk of input) with the weights stationary in registers and
+// two tiles per workgroup requested up front
+bool conv_s2rs_supported(const ConvArgs& a);
+int launch_conv_s2rs(const ConvArgs& a, int num_cus, hipStream_t stream);
+
 // conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
 bool conv_wres_supported(const ConvArgs& a);
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);

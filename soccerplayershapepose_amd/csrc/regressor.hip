@@ -305,7 +305,8 @@ struct spsp_regressor {
     unsigned int* err_dev = nullptr;    // the same word as the kernels see it
     int ief_capacity = 0;               // IEF workgroups the device can hold at once (occupancy x CUs)
     int debug_ief_stall = 0;
-    bool use_s2 = true;                 // stride-2 stages on conv_s2.hip (experiment builds: SPSP_NO_S2 = the ring kernel of round 2)            // test hook (spsp_regressor_debug): the next forward's IEF cannot complete its hand-offs
+    bool use_s2 = true;                 // stride-2 stages on conv_s2.hip (experiment builds: SPSP_NO_S2 = the ring kernel of round 2)
+    bool use_s2rs = true;               // layer2.0 on conv_s2rs.hip (weights stationary in registers); off: conv_s2.hip like the other two
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
 
@@ -348,6 +349,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
+    if (r->use_s2 && r->use_s2rs && conv_s2rs_supported(a)) {   // layer2.0: the same planes, weights stationary in registers
+        ProfScope ps(ctx, kKConvS2, st, true);
+        return launch_conv_s2rs(a, ctx->num_cus, st);
+    }
     if (r->use_s2 && conv_s2_supported(a)) {           // 3x3 / 2 + its 1x1 / 2 downsample in whole 128-pixel tiles: parity-plane patch kernel
         ProfScope ps(ctx, kKConvS2, st, true);
         return launch_conv_s2(a, st);
@@ -643,6 +648,7 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
     switch (what) {
         case SPSP_DEBUG_IEF_STALL: r->debug_ief_stall = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_LAYER4_CHANNELS:
             SPSP_REQUIRE(value == 32 || value == 64, "spsp_regressor_debug: layer4 blocks of %d channels", value);
             r->patch_nch[3] = value;

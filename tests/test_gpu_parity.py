@@ -283,6 +283,33 @@ def test_patch_kernels_with_producer_waves_are_bit_identical(dev):
                     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_layer2_stride2_pair_with_register_stationary_weights_is_bit_identical(dev):
+    """csrc/conv_s2rs.hip: layer2.0's 3x3 / 2 convolution + 1x1 / 2 downsample with the block's weights resident in registers
+    and two 128-pixel tiles per workgroup (`SPSP_DEBUG_PLAN_S2RS`; 0 = conv_s2.hip, the streaming kernel of layer3.0 / layer4.0).
+    Same products accumulated in the same order, so the regressor outputs and layer2's feature map must equal the streaming
+    kernel's bit for bit: B = 32 and 22 (two tiles per workgroup, full and partial grid), 16 and 8 (one tile per workgroup), 3
+    (a grid that is no multiple of 16: the unpaired tile map), both precisions."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec in ('f16', 'bf16'):
+        for B in (32, 22, 16, 8, 3):
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=60 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = []
+            for rs in (0, 1):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2RS, rs), 'debug')
+                out = [t.clone() for t in reg(native)]
+                out.append(reg.read_stage(3, B).clone())
+                torch.cuda.synchronize()
+                reg.check_status()
+                got.append(out)
+            for a, b in zip(*got):
+                assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, monkeypatch):
     """The fit's kinematic chain and reverse sweep run as register-resident walks over quads of lanes (csrc/fit_core.hpp:
     fit_chain_walk, fit_reverse_walk_a / _b -- DPP row broadcasts in place of eight LDS hand-offs per sweep); the level sweeps
