@@ -71,6 +71,10 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src) {      // lanes without a source lane keep `old`
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, 0xf, false);
 }
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_relu16(uint32_t x) {      // max(x, +0) on both 16-bit floats of the pair (bf16 or fp16)
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), i16x2{0, 0}));
+}
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t x, uint32_t y) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y)));
 }
@@ -188,11 +192,13 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
         const int n0 = 4 * st;                                // ring row index of this step's first input row
         if (st + 1 < nsteps) issue_row(n0 + 9 + wave);        // the 4 new rows of the next step, one per wave
 
+        // the accumulators START at the folded BN bias (accumulator element e of tile (i, j) = channel 32 h + 16 i + 4 fq + e):
+        // 64 additions less in the pooling phase, which a lone wave issues at 4-5 cycles each
         f32x4 acc[2][8];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{bias_r[i].x, bias_r[i].y, bias_r[i].z, bias_r[i].w};
 
         // fragment base address per kernel row: input row 2 (conv row) + kr = ring row n0 + 2r + kr
         uint32_t xa[7];
@@ -266,9 +272,11 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 #undef STEM_SB
 
         SSTAMP(3);
-        // ---- horizontal 3 -> 1 max in registers.  bias + ReLU + round to the element type FIRST (all monotone: max commutes
-        // with them), so that the pool runs on packed registers with v_pk_max_u16 -- post-ReLU values are >= +0, and for bf16
-        // and fp16 alike the numeric order of non-negative values is the order of their 16-bit patterns.
+        // ---- horizontal 3 -> 1 max in registers.  Round to the element type FIRST, then ReLU on the packed pairs (all monotone:
+        // max commutes with them; as SIGNED 16-bit integers every negative value, -0 included, is below +0 = 0, so
+        // v_pk_max_i16 against 0 is the ReLU of both element types at half the instructions), so that the pool runs on packed
+        // registers with v_pk_max_u16 -- post-ReLU values are >= +0, and for bf16 and fp16 alike the numeric order of
+        // non-negative values is the order of their 16-bit patterns.
         // Span q: tile a = type 0 (lane n: column 4 (n>>1) + (n&1)), tile b = type 1 (the same + 2).  Pool column 16q + n:
         //   even n = 2m:  max(col 4m-1, 4m, 4m+1) = max(b[n-1], a[n], a[n+1])      (b[-1] = lane 15 of the previous span's b;
         //   odd  n = 2m+1: max(col 4m+1, 4m+2, 4m+3) = max(a[n], b[n-1], b[n])      column -1 is padding: a[0] stands in)
@@ -277,13 +285,12 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
         const bool odd = frow & 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float bv[4] = {bias_r[i].x, bias_r[i].y, bias_r[i].z, bias_r[i].w};
             uint32_t P[8][2];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4 c = acc[i][j];
-                P[j][0] = Elem<F16>::pack2(fmaxf(c[0] + bv[0], 0.f), fmaxf(c[1] + bv[1], 0.f));
-                P[j][1] = Elem<F16>::pack2(fmaxf(c[2] + bv[2], 0.f), fmaxf(c[3] + bv[3], 0.f));
+                P[j][0] = pk_relu16(Elem<F16>::pack2(c[0], c[1]));
+                P[j][1] = pk_relu16(Elem<F16>::pack2(c[2], c[3]));
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

@@ -9,6 +9,7 @@
 
 #include "smpl.hpp"
 #include "fit_core.hpp"
+#include "geometry_device.hpp"
 
 namespace {
 using namespace spsp;
@@ -32,15 +33,22 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
                                                  float* __restrict__ betas, float* __restrict__ cam,
                                                  const float* __restrict__ joints2d, float* __restrict__ loss_hist,
                                                  float* __restrict__ l2e_hist, float* __restrict__ param_hist,
-                                                 unsigned long long* __restrict__ dbg) {
+                                                 const spsp::FitEnds E, unsigned long long* __restrict__ dbg) {
     __shared__ FitShared s;
+    __shared__ float sR0[216];
     FitLane r;
     const int lane = threadIdx.x, b = blockIdx.x;
     const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     float* Rb = R + (size_t)b * 216;
     float* bb = betas + (size_t)b * 10;
     float* cb = cam + (size_t)b * 3;
-    fit_init(s, r, lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb, cb,
+    const float* Rsrc = Rb;
+    if (E.pose6d) {      // straight from the regressor: the 24 rotation matrices are built here (spsp_rot6d_to_rotmat's statements)
+        if (lane < 24) rot6d_one(E.pose6d + ((size_t)b * 24 + lane) * 6, sR0 + lane * 9);
+        __syncthreads();
+        Rsrc = sR0;
+    }
+    fit_init(s, r, lane, fitc, parents, level_joints, level_start, child_start, child_list, Rsrc, bb, cb,
              joints2d + (size_t)b * 34, P.param_mask, WALK ? walk : nullptr);
     __syncthreads();
     float* lh = loss_hist ? loss_hist + (size_t)b * P.iters : nullptr;
@@ -121,7 +129,11 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         if (p < kPrmR) cb[p] = v;
         else if (p < kPrmBeta) Rb[p - kPrmR] = v;
         else bb[p - kPrmBeta] = v;
+        // the all-gather payload [cam | R | betas] is this very array (spsp_pack_record)
+        if (E.record) E.record[(size_t)b * kNumPrm + p] = v;
     }
+    if (E.translation && lane < 3)      // spsp_wp_to_translation's statement on the returned camera
+        E.translation[(size_t)b * 3 + lane] = wp_translation(src[0], src[1], src[2], E.focal, E.resolution, lane);
 }
 
 }  // namespace
@@ -155,7 +167,15 @@ int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, 
 
 int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
                         const float* joints2d, int B, float* loss_hist, float* l2e_hist, float* param_hist, void* stream) {
-    using namespace spsp;
+    return spsp::fit_launch(ctx, s, cfg, R, betas, cam, joints2d, B, loss_hist, l2e_hist, param_hist, spsp::FitEnds{}, stream);
+}
+
+}  // extern "C"
+
+namespace spsp {
+
+int fit_launch(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam, const float* joints2d,
+               int B, float* loss_hist, float* l2e_hist, float* param_hist, const FitEnds& ends, void* stream) {
     SPSP_REQUIRE(ctx && s && cfg, "spsp_fit: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     SPSP_REQUIRE(B >= 0, "spsp_fit: negative batch");
@@ -186,7 +206,7 @@ int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg,
 #endif
 #define SPSP_FIT_LAUNCH(WALK)                                                                                                        \
     launch_kernel(&fit_kernel<WALK>, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,  \
-                  s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, dbg)
+                  s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg)
     // (the level sweeps remain for models whose tree is not SMPL's; the variable is the A/B switch of tests and tools)
     if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS")) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
 #undef SPSP_FIT_LAUNCH
@@ -203,4 +223,4 @@ int spsp_fit_trajectory(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg,
     return SPSP_OK;
 }
 
-}  // extern "C"
+}  // namespace spsp

@@ -1,30 +1,15 @@
 // Small per-player geometry kernels: rot6d -> rotmat, weak-perspective projection, camera
 // conversion, record pack/unpack.  All are trivially HBM/latency bound (SURVEY 8a a5,a7,a12).
 #include "common.hpp"
+#include "geometry_device.hpp"
 
 namespace {
 
-// rot6d_to_rotmat, PR/utils/rigid_transform_utils.py:27-41.  x.view(-1,3,2): a1 = x[0,2,4],
-// a2 = x[1,3,5]; F.normalize divides by max(||v||, 1e-12); columns of R are (b1, b2, b3).
+// rot6d_to_rotmat, PR/utils/rigid_transform_utils.py:27-41 (the formula: geometry_device.hpp)
 __global__ void rot6d_kernel(const float* __restrict__ x, int n, float* __restrict__ R) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* p = x + (size_t)i * 6;
-    float a1x = p[0], a1y = p[2], a1z = p[4];
-    float a2x = p[1], a2y = p[3], a2z = p[5];
-    float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
-    float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
-    float d = b1x * a2x + b1y * a2y + b1z * a2z;
-    float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
-    float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
-    float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
-    float b3x = b1y * b2z - b1z * b2y;
-    float b3y = b1z * b2x - b1x * b2z;
-    float b3z = b1x * b2y - b1y * b2x;
-    float* o = R + (size_t)i * 9;
-    o[0] = b1x; o[1] = b2x; o[2] = b3x;
-    o[3] = b1y; o[4] = b2y; o[5] = b3y;
-    o[6] = b1z; o[7] = b2z; o[8] = b3z;
+    spsp::rot6d_one(x + (size_t)i * 6, R + (size_t)i * 9);
 }
 
 // orthographic_project_torch (+ undo_keypoint_normalisation), PR/utils/cam_utils.py:5-26.
@@ -50,9 +35,9 @@ __global__ void project_kernel(const float* __restrict__ pts, const float* __res
 __global__ void wp2t_kernel(const float* __restrict__ cam, int B, float focal, float res, float* __restrict__ t) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    t[b * 3 + 0] = cam[b * 3 + 1];
-    t[b * 3 + 1] = cam[b * 3 + 2];
-    t[b * 3 + 2] = 2.f * focal / (res * cam[b * 3 + 0] + 1e-9f);
+    const float s = cam[b * 3 + 0], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[b * 3 + i] = spsp::wp_translation(s, tx, ty, focal, res, i);
 }
 
 __global__ void pack_record_kernel(const float* __restrict__ cam, const float* __restrict__ R,

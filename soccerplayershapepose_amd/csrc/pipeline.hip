@@ -3,7 +3,7 @@
 //   [-> packed [cam | R | betas] record for the all-gather].
 // Nothing new is computed here: it issues the launches of the stage entry points, in their order, on the caller's
 // stream -- what player_recon.reconstruct_players does through six ctypes calls.  Every buffer is the caller's.
-#include "common.hpp"
+#include "smpl.hpp"
 
 extern "C" {
 
@@ -20,6 +20,17 @@ int spsp_pipeline(spsp_ctx* ctx, spsp_regressor* regressor, spsp_smpl* smpl, sps
 #define TRY(x) do { rc = (x); if (rc != SPSP_OK) return rc; } while (0)
     TRY(spsp_regressor_forward(ctx, regressor, proxy, proxy_format, B, out->cam, out->pose6d, out->betas, nullptr, stream));
     float* R = out->rotmats;
+    if (fit && !relate) {
+        // the fit kernel builds R from pose6d on its way in and writes the translation and the record on its way out: three
+        // launches (and their boundaries) less in the tail of the chain, the same statements (geometry_device.hpp)
+        spsp::FitEnds ends;
+        ends.pose6d = out->pose6d;
+        ends.translation = out->translation; ends.focal = focal; ends.resolution = resolution;
+        ends.record = out->record;
+        TRY(spsp::fit_launch(ctx, smpl, fit, R, out->betas, out->cam, joints2d, B, nullptr, nullptr, nullptr, ends, stream));
+        if (out->vertices || out->joints) TRY(spsp_smpl_forward(ctx, smpl, R, out->betas, B, out->vertices, out->joints, stream));
+        return SPSP_OK;
+    }
     if (relate) {      // rot6d -> tmp, relation module tmp -> rotmats (it may not run in place)
         TRY(spsp_rot6d_to_rotmat(ctx, out->pose6d, B * 24, out->relate_tmp, stream));
         TRY(spsp_relate_forward(ctx, relate, out->relate_tmp, boxes, B, R, stream));

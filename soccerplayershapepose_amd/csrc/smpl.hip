@@ -3,11 +3,11 @@
 // -> smplx.lbs.lbs [EXT]).  VALU fp32 on purpose: the contraction is [B<=32..256] x 217 -- far too thin
 // for MFMA; the kernel is bound by streaming the 17.9 MB blend basis (HBM / Infinity Cache).
 //
-//   chain kernel   one wavefront per player: coef = [betas | R[1:]-I], J = Jbar + JS.betas, level-parallel
-//                  kinematic chain in LDS, rel. transforms A[24][3x4], posed joints 0..23.
 //   skin kernel    one thread per vertex, PB players per workgroup kept in registers so every basis row is
-//                  read ONCE per PB players; coef and A staged in LDS (broadcast reads); joint-major
-//                  LBS weights for coalesced loads.
+//                  read ONCE per PB players; coef = [betas | R[1:]-I] and the transforms A in LDS (broadcast reads);
+//                  joint-major LBS weights for coalesced loads.  Eight more waves per workgroup compute the players'
+//                  kinematic chains meanwhile (J = Jbar + JS.betas, level-parallel chain in LDS, rel. transforms
+//                  A[24][3x4], posed joints 0..23) -- a kernel of its own until round 4.
 //   joints kernel  21 picked vertices + 45 regressed joints (CSR of the dense regressor rows) from the
 //                  FINAL vertices, as the reference does (smpl_official.py:30-34).
 #include <algorithm>
@@ -20,78 +20,107 @@
 namespace {
 using namespace spsp;
 
-constexpr int kSkinThreads = 256;
+constexpr int kSkinThreads = 256;     // the four accumulating / skinning waves
+constexpr int kChainWaves = 8;        // + one wave per player that turns its (R, betas) into the skinning transforms (two waves with four
+                                      // players each, one after the other, took as long as the blend phase: a chain is ~2.5 us of latency)
+constexpr int kSkinBlock = kSkinThreads + 64 * kChainWaves;
 constexpr int kPB = 8;   // players per skin workgroup (16 measured slower in round 3: 27.7 vs 19.0 us -- 236 VGPRs and 82 KB of LDS leave one workgroup of four waves per CU)
+static_assert(kPB % kChainWaves == 0, "players split evenly over the chain waves");
 
-__global__ __launch_bounds__(64) void smpl_chain_kernel(const float* __restrict__ R, const float* __restrict__ betas,
-                                                        const float* __restrict__ jconst,
-                                                        const int* __restrict__ parents,
-                                                        const int* __restrict__ level_joints,
-                                                        const int* __restrict__ level_start, int num_levels,
-                                                        float* __restrict__ A_out, float* __restrict__ coef_out,
-                                                        float* __restrict__ joints_out) {
-    __shared__ float sR[216], sBeta[16], sJ[72], sW[288], sJc[792];
-    __shared__ TreeLds tree;
-    const int b = blockIdx.x, lane = threadIdx.x;
-    load_tree(tree, parents, level_joints, level_start, num_levels, lane);
-    for (int i = lane; i < 216; i += 64) sR[i] = R[(size_t)b * 216 + i];
-    if (lane < 10) sBeta[lane] = betas[b * 10 + lane];
-    for (int i = lane; i < 792; i += 64) sJc[i] = jconst[i];
-    __syncthreads();
-    // blend coefficients: betas, then pose feature (R[1:] - I) flattened row-major (smplx lbs, pose2rot=False)
-    for (int i = lane; i < kNCoef; i += 64) {
-        float v;
-        if (i < 10) v = sBeta[i];
-        else {
-            int j = i - 10, e = j % 9;
-            v = sR[9 + j] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
-        }
-        coef_out[(size_t)b * kNCoef + i] = v;
-    }
-    joints_from_betas(sJc, sJc + 72, sBeta, sJ, lane);
-    __syncthreads();
-    chain_forward(sR, sJ, sW, tree, lane);
-    // A_k = [W_k.R | W_k.t - W_k.R J_k]; posed joint k = W_k.t
+// Per chain wave: one player's rotation matrices / joints / world transforms.
+struct ChainLds {
+    float R[216], beta[16], J[72], W[288];
+};
+
+// One wavefront, one player: J = Jbar + JS . betas, the level-parallel kinematic chain, A_k = [W_k.R | W_k.t - W_k.R J_k]
+// (smplx batch_rigid_transform); the posed joints 0..23 are W_k.t.  Until round 4 this was a kernel of its own (one wavefront
+// per player, 10.6 us + a launch boundary in front of the skin kernel -- part of the serial tail every pipeline slot waits
+// for); now eight extra waves of every skin workgroup run it, one player each, WHILE the other four stream the blend
+// basis.  Same statements in the same order as before: bit-identical transforms.  Everything it reads from global memory
+// (R, betas, the joint constants, the tree) is fetched BEFORE the workgroup's first barrier: a dependent global round trip
+// behind the blend loop's loads takes microseconds (first version: the skin kernel 19.5 -> 29 us, as long as both kernels).
+__device__ __forceinline__ void chain_one_player(ChainLds& c, const float* sJc, const TreeLds& tree, float* A_lds, float* A_out,
+                                                 float* joints_out, int lane) {
+    joints_from_betas(sJc, sJc + 72, c.beta, c.J, lane);
+    lds_phase_sync<true>();
+    chain_forward<true>(c.R, c.J, c.W, tree, lane);
     for (int o = lane; o < 72; o += 64) {
-        int k = o / 3, i = o % 3;
-        const float* w = sW + k * 12 + i * 4;
-        float t = w[3] - (w[0] * sJ[k * 3] + w[1] * sJ[k * 3 + 1] + w[2] * sJ[k * 3 + 2]);
-        float* a = A_out + ((size_t)b * 24 + k) * 12 + i * 4;
+        const int k = o / 3, i = o % 3;
+        const float* w = c.W + k * 12 + i * 4;
+        const float t = w[3] - (w[0] * c.J[k * 3] + w[1] * c.J[k * 3 + 1] + w[2] * c.J[k * 3 + 2]);
+        float* a = A_lds + k * 12 + i * 4;
         a[0] = w[0]; a[1] = w[1]; a[2] = w[2]; a[3] = t;
-        if (joints_out) joints_out[((size_t)b * SPSP_NUM_OUT_JOINTS + k) * 3 + i] = w[3];
+        if (A_out) { float* g = A_out + k * 12 + i * 4; g[0] = w[0]; g[1] = w[1]; g[2] = w[2]; g[3] = t; }
+        if (joints_out) joints_out[k * 3 + i] = w[3];
     }
 }
 
 // Workgroup = 4 waves over the SAME 64 vertices and kPB players: wave w accumulates rows [55w, 55w+55) of the
 // 217-row blend basis (split-K: 4x more waves and 4x shorter dependent-load chains at no extra basis traffic),
 // partial sums meet in LDS, then wave w skins players (kPB / 4) w .. + kPB / 4 - 1.
-__global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __restrict__ basis,
-                                                                 const float* __restrict__ v_template,
-                                                                 const float* __restrict__ wT,
-                                                                 const float* __restrict__ A,
-                                                                 const float* __restrict__ coef, int B,
-                                                                 float* __restrict__ verts, float* __restrict__ vposed) {
+// Waves 4..11 (round 4): the kinematic chain of one of the workgroup's players each (chain_one_player), into sA -- and, from the
+// workgroups of the first vertex tile, into the handle's A workspace (the VJP reads it) and joints 0..23.
+__global__ __launch_bounds__(kSkinBlock) void smpl_skin_kernel(const float* __restrict__ basis,
+                                                               const float* __restrict__ v_template,
+                                                               const float* __restrict__ wT,
+                                                               const float* __restrict__ R, const float* __restrict__ betas,
+                                                               const float* __restrict__ jconst,
+                                                               const int* __restrict__ parents, const int* __restrict__ level_joints,
+                                                               const int* __restrict__ level_start, int num_levels,
+                                                               float* __restrict__ A_ws, float* __restrict__ joints_out, int B,
+                                                               float* __restrict__ verts, float* __restrict__ vposed) {
     __shared__ float sCoef[kPB][kNCoef + 3];
     __shared__ __attribute__((aligned(16))) float sA[kPB][288];
     __shared__ float sPart[4][kPB * 3][64];                // [k-slice][player*3 + c][lane]
-    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
-    const int b0 = blockIdx.y * kPB;
+    __shared__ ChainLds sChain[kChainWaves];
+    __shared__ TreeLds sTree;
+    __shared__ float sJc[792];
+    const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int vtile = (int)blockIdx.x, grp = (int)blockIdx.y;
+    const int b0 = grp * kPB;
     const int nb = min(kPB, B - b0);
-    for (int i = threadIdx.x; i < kPB * kNCoef; i += kSkinThreads) {
-        int p = i / kNCoef, j = i % kNCoef;
-        sCoef[p][j] = (p < nb) ? coef[(size_t)(b0 + p) * kNCoef + j] : 0.f;
+    if (ks >= 4) {
+        static_assert(kChainWaves == kPB, "one chain wave per player");
+        ChainLds& c = sChain[ks - 4];
+        const int p = ks - 4;
+        const size_t b = b0 + (p < nb ? p : 0);
+        if (ks == 4) load_tree(sTree, parents, level_joints, level_start, num_levels, lane);
+        for (int i = threadIdx.x - kSkinThreads; i < 792; i += 64 * kChainWaves) sJc[i] = jconst[i];
+        for (int i = lane; i < 216; i += 64) c.R[i] = R[b * 216 + i];
+        if (lane < 10) c.beta[lane] = betas[b * 10 + lane];
+        __syncthreads();                                   // (the staging barrier of the other waves)
+        const bool first = vtile == 0;
+        if (p < nb)
+            chain_one_player(c, sJc, sTree, &sA[p][0], first ? A_ws + b * 288 : nullptr,
+                             (first && joints_out) ? joints_out + b * SPSP_NUM_OUT_JOINTS * 3 : nullptr, lane);
+        else
+            for (int i = lane; i < 288; i += 64) sA[p][i] = 0.f;
+        __syncthreads();                                   // (the barrier in front of the skinning: sA is complete)
+        return;
     }
-    for (int i = threadIdx.x; i < kPB * 288; i += kSkinThreads) {
-        int p = i / 288, j = i % 288;
-        sA[p][j] = (p < nb) ? A[(size_t)(b0 + p) * 288 + j] : 0.f;
+    // blend coefficients: betas, then the pose feature (R[1:] - I) flattened row-major (smplx lbs, pose2rot=False)
+    for (int i = threadIdx.x; i < kPB * kNCoef; i += kSkinThreads) {
+        const int p = i / kNCoef, j = i % kNCoef;
+        float v = 0.f;
+        if (p < nb) {
+            if (j < 10) v = betas[(size_t)(b0 + p) * 10 + j];
+            else {
+                const int jj = j - 10, e = jj % 9;
+                v = R[(size_t)(b0 + p) * 216 + 9 + jj] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            }
+        }
+        sCoef[p][j] = v;
     }
     __syncthreads();
-    const int v = min(blockIdx.x * 64 + lane, kV - 1);
+    const int v = min(vtile * 64 + lane, kV - 1);
     float px[kPB], py[kPB], pz[kPB];
 #pragma unroll
     for (int p = 0; p < kPB; ++p) px[p] = py[p] = pz[p] = 0.f;
     constexpr int kRows = (kNCoef + 3) / 4;                 // 55 rows per slice (last slice: 52)
     const int j0 = ks * kRows, j1 = min(j0 + kRows, kNCoef);
+    // (measured in round 4, all within 1 us of each other: coordinate PLANES of the basis -- 256 contiguous bytes per load instead
+    //  of every third float of 768 --, the player groups of a vertex tile on one XCD, 11 or 18 rows per unrolled batch; the
+    //  joint loop below fully unrolled spilled: 64 us)
     const float* bp = basis + 3 * v;
 #pragma unroll 5
     for (int j = j0; j < j1; ++j) {
@@ -113,7 +142,7 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
     __syncthreads();
     // skinning: this wave takes players NQ ks .. NQ ks + NQ - 1.  T = sum_k w[v][k] A_k (3x4), vert = T [v_posed; 1]
     constexpr int NQ = kPB / 4;
-    const bool vok = blockIdx.x * 64 + lane < kV;
+    const bool vok = vtile * 64 + lane < kV;
     float qx[NQ], qy[NQ], qz[NQ], ox[NQ], oy[NQ], oz[NQ];
     const float t0 = v_template[3 * v], t1 = v_template[3 * v + 1], t2 = v_template[3 * v + 2];
 #pragma unroll
@@ -124,7 +153,7 @@ __global__ __launch_bounds__(kSkinThreads) void smpl_skin_kernel(const float* __
         qz[q] = t2 + ((sPart[0][p * 3 + 2][lane] + sPart[1][p * 3 + 2][lane]) + (sPart[2][p * 3 + 2][lane] + sPart[3][p * 3 + 2][lane]));
         ox[q] = oy[q] = oz[q] = 0.f;
         // (the differentiable path keeps the posed rest vertex: d vertex / d A_k needs it, smpl_vjp.hip)
-        if (vposed && p < nb && blockIdx.x * 64 + lane < kV) {
+        if (vposed && p < nb && vok) {
             float* o = vposed + ((size_t)(b0 + p) * kV + v) * 3;
             o[0] = qx[q]; o[1] = qy[q]; o[2] = qz[q];
         }
@@ -225,7 +254,6 @@ int spsp_smpl_load(spsp_ctx* ctx, const spsp_smpl_arrays* a, int max_batch, spsp
     TRY(s->pool.upload(&s->csr_val, h.csr_val.data(), h.csr_val.size()));
     TRY(s->pool.upload(&s->fitc, h.fitc.data(), h.fitc.size()));
     TRY(s->pool.alloc(&s->ws_A, (size_t)max_batch * 288));
-    TRY(s->pool.alloc(&s->ws_coef, (size_t)max_batch * kNCoef));
     TRY(s->pool.alloc(&s->ws_verts, (size_t)max_batch * kV3));
 #undef TRY
     *out = s;
@@ -252,14 +280,11 @@ int smpl_forward_impl(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
     SPSP_REQUIRE(B >= 0 && B <= s->max_batch, "spsp_smpl_forward: B=%d exceeds max_batch=%d", B, s->max_batch);
     if (B == 0 || (!verts && !joints)) return SPSP_OK;
     hipStream_t st = as_stream(stream);
-    { ProfScope ps(ctx, kKSmplChain, st, true);
-    launch_kernel(&smpl_chain_kernel, dim3(B), dim3(64), 0, st, R, betas, s->jconst, s->parents, s->level_joints, s->d_level_start,
-                                        s->num_levels, s->ws_A, s->ws_coef, joints); }
-    SPSP_HIP_CHECK(hipGetLastError());
     float* v = verts ? verts : s->ws_verts;
     dim3 grid((kV + 63) / 64, (B + kPB - 1) / kPB);
     { ProfScope ps(ctx, kKSmplSkin, st, true);
-      launch_kernel(&smpl_skin_kernel, grid, dim3(kSkinThreads), 0, st, s->basis, s->v_template, s->wT, s->ws_A, s->ws_coef, B, v, vposed); }
+      launch_kernel(&smpl_skin_kernel, grid, dim3(kSkinBlock), 0, st, s->basis, s->v_template, s->wT, R, betas, s->jconst, s->parents,
+                    s->level_joints, s->d_level_start, s->num_levels, s->ws_A, joints, B, v, vposed); }
     SPSP_HIP_CHECK(hipGetLastError());
     if (joints) {
         ProfScope ps(ctx, kKSmplJoints, st, true);

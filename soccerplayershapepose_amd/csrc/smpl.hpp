@@ -32,7 +32,6 @@ struct spsp_smpl {
     int face_ids[spsp::kNFace];
     // workspace
     float* ws_A;         // [max_batch][24][12]
-    float* ws_coef;      // [max_batch][217]
     float* ws_verts;     // [max_batch][6890][3] (only used when the caller passes verts == NULL)
     int host_parents[24];
     // differentiable path (smpl_vjp.hip, fit_sil.hip), allocated at first use
@@ -47,6 +46,19 @@ struct spsp_smpl {
 };
 
 namespace spsp {
+// What spsp_pipeline lets the fit kernel do at its two ends instead of launching three more kernels around it (each ~4 us plus
+// a launch boundary of the serial tail a pipeline slot waits for):
+//   pose6d      [B,144] the regressor's 6-D rotations: R is built from them in the kernel (spsp_rot6d_to_rotmat) -- the R
+//               argument is then output only;
+//   translation [B,3]   spsp_wp_to_translation of the returned camera;      record [B,229] spsp_pack_record of the returned state.
+struct FitEnds {
+    const float* pose6d = nullptr;
+    float* translation = nullptr;
+    float focal = 0.f, resolution = 0.f;
+    float* record = nullptr;
+};
+int fit_launch(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam, const float* joints2d,
+               int B, float* loss_hist, float* l2e_hist, float* param_hist, const FitEnds& ends, void* stream);
 int smpl_forward_impl(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* betas, int B, float* verts, float* joints,
                       float* vposed, void* stream);
 int smpl_vjp_workspace(spsp_smpl* s);

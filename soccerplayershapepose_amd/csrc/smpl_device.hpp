@@ -41,14 +41,30 @@ __device__ __forceinline__ void joints_from_betas(const float* Jbar, const float
     }
 }
 
+// Orders the LDS writes of one phase against the reads of the next.  WAVE = false: the workgroup is ONE wavefront and
+// __syncthreads() is that wave's barrier; WAVE = true: the caller is one wavefront of a larger workgroup working on LDS of its
+// own -- a wave issues its LDS instructions in order, so only the COMPILER has to be kept from moving a read above another
+// lane's write: wavefront-scope release / acquire around a wave barrier (no instruction is emitted for it; fit.hip).
+template <bool WAVE>
+__device__ __forceinline__ void lds_phase_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // Kinematic chain (smplx batch_rigid_transform): W_0 = [R_0 | J_0], W_k = W_parent * [R_k | J_k - J_parent].
 // Rm [24][9] row-major, J [24][3], W [24][12] row-major 3x4.  Level-parallel: 5 joints x 12 elements per pass.
+template <bool WAVE = false>
 __device__ __forceinline__ void chain_forward(const float* Rm, const float* J, float* W, const TreeLds& t, int lane) {
     if (lane < 12) {
         int i = lane >> 2, c = lane & 3;
         W[lane] = (c < 3) ? Rm[i * 3 + c] : J[i];
     }
-    __syncthreads();
+    lds_phase_sync<WAVE>();
     const int slot = lane / 12, e = lane % 12;
     const int i = e >> 2, c = e & 3;
     for (int l = 1; l < t.num_levels; ++l) {
@@ -72,7 +88,7 @@ __device__ __forceinline__ void chain_forward(const float* Rm, const float* J, f
                 W[k * 12 + e] = acc;
             }
         }
-        __syncthreads();
+        lds_phase_sync<WAVE>();
     }
 }
 
