@@ -1,8 +1,11 @@
 // GPU driver of the reprojection fit: one 256-thread workgroup (4 wavefronts) per player, all iterations in one launch, state in
-// LDS (14 KB), Adam moments and the model constants a lane multiplies with in registers (one parameter per lane).  The
-// arithmetic lives in fit_core.hpp (shared with the host emulation used by the CPU tests).  Latency-bound by design: ten
-// workgroup barriers per iteration, the two tree sweeps as register-resident walks inside wavefront 0.  Players are
-// independent, so a batch holds one CU per player.  (Four players per workgroup -- 8 CUs per batch -- was built and measured in
+// LDS (19 KB), Adam moments and the model constants a lane multiplies with in registers (one parameter per lane).  The
+// arithmetic lives in fit_core.hpp (shared with the host emulation used by the CPU tests).  Latency-bound by design: the two
+// tree sweeps as register-resident walks inside wavefront 0.  Players are independent, so a batch holds one CU per player.
+// Round 4: fit_kernel2 -- the same operations on a shorter critical path (eight workgroup barriers per iteration instead of
+// ten, a rotation entry's Adam step in the lane that computed its gradient, waves 1 and 3 working beside wave 0's walks;
+// fit_core.hpp "round 4"): 7.6 k instead of 8.4 k cycles per iteration, 186 -> 164 us for 50 iterations, every iterate
+// bit-identical.  fit_kernel<WALK> keeps the ten-barrier schedule (models with another tree; the A/B switch of the tests).  (Four players per workgroup -- 8 CUs per batch -- was built and measured in
 // round 3: the fit got 1.5 x longer and the four-slot pipeline slower, because a slot's stream waits for its fit)
 #include <cmath>
 #include <cstdlib>
@@ -136,6 +139,93 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel(FitParams P, const
         E.translation[(size_t)b * 3 + lane] = wp_translation(src[0], src[1], src[2], E.focal, E.resolution, lane);
 }
 
+// The v2 schedule of the same fit (fit_core.hpp, "round 4"): eight workgroup barriers per iteration, the Adam step of a rotation
+// entry in the lane that computed its gradient, wave 1 / wave 3 working beside the tree walks of wave 0.  SMPL's tree only (the
+// walks are compiled for it); every iterate bit-identical to fit_kernel<true>.
+__global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel2(FitParams P, const uint32_t* __restrict__ walk, const float* __restrict__ fitc,
+                                                  const int* __restrict__ parents, const int* __restrict__ level_joints,
+                                                  const int* __restrict__ level_start, const int* __restrict__ child_start,
+                                                  const int* __restrict__ child_list, float* __restrict__ R,
+                                                  float* __restrict__ betas, float* __restrict__ cam,
+                                                  const float* __restrict__ joints2d, float* __restrict__ loss_hist,
+                                                  float* __restrict__ l2e_hist, float* __restrict__ param_hist,
+                                                  const spsp::FitEnds E, unsigned long long* __restrict__ dbg) {
+    __shared__ FitShared s;
+    __shared__ Fit2Shared x;
+    __shared__ float sR0[216];
+    FitLane r;
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Rb = R + (size_t)b * 216;
+    float* bb = betas + (size_t)b * 10;
+    float* cb = cam + (size_t)b * 3;
+    const float* Rsrc = Rb;
+    if (E.pose6d) {      // straight from the regressor: the 24 rotation matrices are built here (spsp_rot6d_to_rotmat's statements)
+        if (lane < 24) rot6d_one(E.pose6d + ((size_t)b * 24 + lane) * 6, sR0 + lane * 9);
+        __syncthreads();
+        Rsrc = sR0;
+    }
+    fit_init(s, r, lane, fitc, parents, level_joints, level_start, child_start, child_list, Rsrc, bb, cb,
+             joints2d + (size_t)b * 34, P.param_mask, walk);
+    fit2_init0(x, lane);
+    __syncthreads();
+    fit2_init(s, x, r, lane, fitc, P.param_mask);
+    __syncthreads();
+    float* lh = loss_hist ? loss_hist + (size_t)b * P.iters : nullptr;
+    float* eh = l2e_hist ? l2e_hist + (size_t)b * P.iters : nullptr;
+    double b1t = 1.0, b2t = 1.0;
+    const float w1 = (float)(1.0 - P.beta1), b2f = (float)P.beta2, w2 = (float)(1.0 - P.beta2), epsf = (float)P.eps;
+    for (int it = 0; it < P.iters; ++it) {
+        b1t *= P.beta1;
+        b2t *= P.beta2;
+        const float step_size = (float)(P.lr / (1.0 - b1t));
+        const float bc2_sqrt = (float)sqrt(1.0 - b2t);
+        float* const ph = param_hist ? param_hist + ((size_t)b * P.iters + it) * kNumPrm : nullptr;
+        STAMP(0);
+        fit2_p1(s, x, r, lane);                                      __syncthreads();
+        STAMP(1);
+        if (wave == 0) fit_chain_walk(s, r, lane);
+        else if (wave == 1) fit2_vp(s, lane);
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
+        fit_p4(s, r, lane);                                          __syncthreads();
+        STAMP(4);
+        if (wave == 0) fit2_p6(s, lane, P);
+        STAMP(5);
+        __syncthreads();
+        fit_p7(s, r, lane);                                          __syncthreads();
+        STAMP(6);
+        if (wave == 0) {
+            fit_reverse_walk_a(s, r, lane);
+            wave_phase_fence();
+            fit_reverse_walk_b(s, r, lane);
+        } else if (wave == 1) fit_p8(s, lane - 64, P, it, lh, eh);
+        STAMP(7);
+        __syncthreads();
+        fit2_dj(s, r, lane);
+        __syncthreads();
+        STAMP(8);
+        if (wave == 3) { fit2_p11a(s, x, lane); wave_phase_fence(); }
+        const float g_rot = fit2_dr(s, r, lane);
+        fit2_step(s, x, r, lane, g_rot, w1, b2f, w2, epsf, step_size, bc2_sqrt, ph);
+        STAMP(9);
+        __syncthreads();
+        STAMP(10);
+    }
+    const float* src = (P.select_mode == SPSP_FIT_SELECT_BEST_L2E) ? s.best : s.prm;
+    if (lane < kNumPrm) {
+        const int p = lane;
+        const float v = src[p];
+        if (p < kPrmR) cb[p] = v;
+        else if (p < kPrmBeta) Rb[p - kPrmR] = v;
+        else bb[p - kPrmBeta] = v;
+        if (E.record) E.record[(size_t)b * kNumPrm + p] = v;
+    }
+    if (E.translation && lane < 3)
+        E.translation[(size_t)b * 3 + lane] = wp_translation(src[0], src[1], src[2], E.focal, E.resolution, lane);
+}
+
 }  // namespace
 
 extern "C" {
@@ -207,8 +297,13 @@ int fit_launch(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R
 #define SPSP_FIT_LAUNCH(WALK)                                                                                                        \
     launch_kernel(&fit_kernel<WALK>, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,  \
                   s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg)
-    // (the level sweeps remain for models whose tree is not SMPL's; the variable is the A/B switch of tests and tools)
-    if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS")) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
+    // (the level sweeps remain for models whose tree is not SMPL's; the variables are the A/B switches of tests and tools:
+    //  SPSP_FIT_SCHEDULE=1 = the ten-barrier schedule of rounds 1-3 with the walks, SPSP_FIT_LEVEL_SWEEPS = with the level sweeps)
+    const char* sched = getenv("SPSP_FIT_SCHEDULE");
+    if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS") && !(sched && sched[0] == '1'))
+        launch_kernel(&fit_kernel2, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,
+                      s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg);
+    else if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS")) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
 #undef SPSP_FIT_LAUNCH
     if (dbg) {
         unsigned long long h[16];

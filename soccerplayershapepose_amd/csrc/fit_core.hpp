@@ -103,16 +103,16 @@ struct alignas(16) FitShared {
     float Jrel[72];          // J_k - J_parent(k) (root: J_0)
     float best[232];
     float grad[232];
-    float vp[16];
+    alignas(16) float vp[16];
     float xf[16];
     float g[34];
     float ga[72];            // dL/d(tw_k) seeds of the chain joints that are fit targets (others stay 0; z stays 0)
-    float h[16];             // dL/d(x_v) of the 5 face vertices (z stays 0)
+    alignas(16) float h[16]; // dL/d(x_v) of the 5 face vertices (z stays 0)
     float rpart[17 * 5];     // per-fit-joint partials: loss, l2e, gs, gtx, gty
     float red[8];            // reduced: loss, l2e, gs, gtx, gty
     float adir[72];          // direct part of abar
     float dJ[72];
-    float adj[96];           // [dvp(15) | dJ_total(72) | 0(9)]: what d(beta) contracts with fc[kFcC]
+    alignas(16) float adj[96];   // [dvp(15) | dJ_total(72) | 0(9)]: what d(beta) contracts with fc[kFcC]
     float tgt_px[34];
     float best_l2e;
     int take_best;
@@ -712,6 +712,278 @@ SPSP_HD void fit_p12(FitShared& s, FitLane& r, int lane, float w1, float b2, flo
     r.v = r.v * b2 + (w2 * g) * g;
     const float denom = sqrtf(r.v) / bc2_sqrt + eps;
     s.prm[p] = cur + ((-step_size) * r.m) / denom;
+}
+
+// ==== round 4: the SAME arithmetic on a shorter critical path (schedule "v2"; fit.hip, fit_kernel2) ==========================
+// The phases above run P12 | P1 | P2 | chain | P4 | P6 | P7 | P8 + reverse | P10 | P11 | with a workgroup barrier at every bar: ten
+// LDS hand-offs per Adam iteration, 8.4 k cycles (stamps of round 3).  Nothing below changes a formula or the order of the
+// operations that produce a value -- every iterate stays BIT-IDENTICAL to the phases above (tests/emul runs both side by side,
+// the GPU test compares all iterates) -- only WHO computes it WHEN:
+//   * a parameter belongs to the lane that computes its gradient (rotation entry e: lane e, camera: lanes 216..218, betas: lanes
+//     219..228), so the Adam step of the 216 rotation entries follows their gradient in the same lane, in registers: no
+//     gradient array hand-off, no barrier between P10 and P12;
+//   * the Adam step PUBLISHES the new value in every form the next iteration reads (prm, the chain operand Mt, the reverse
+//     operand Tt), P1 publishes J_0 and J_k - J_parent into W_0 / Mt / Tt: P2 shrinks to the 15 face-vertex sums, which wave 1
+//     finishes while wave 0 walks the chain;
+//   * P8 (sums of the dvp partials, loss history, best-iterate decision) runs on wave 1 while wave 0 walks the tree back;
+//   * d(beta) (P11) runs inside wave 3 (4 chunks per lane instead of 1, the 16 partial sums and their final tree unchanged)
+//     in front of that wave's Adam steps, while the other waves step theirs: one workgroup barrier and one Adam latency less.
+// Eight barriers per iteration.
+struct alignas(16) Fit2Shared {
+    alignas(16) float cC[10 * 96];     // d(beta) coefficients, row i = beta_i over adj[0..95] (fitc[kFcC], pitch 96: ds_read_b128)
+    alignas(16) float beta4[12];       // the betas again, 16-byte aligned: P1 reads them with three ds_read_b128 instead of ten b32
+    alignas(16) float pf[16 * 16];     // the pose feature entries R[1:] in P1's chunks of 13, one chunk per 16 floats (four b128)
+};
+
+SPSP_HD int fit2_owned_param(int lane) {
+    return lane < 216 ? lane + kPrmR : (lane < 219 ? lane - 216 : (lane < kNumPrm ? lane : -1));
+}
+
+// the forms of rotation entry p (kPrmR <= p < kPrmBeta) the sweeps read.  NOT W_0: the rotation gradients of this very phase
+// still read the root transform; fit2_p1 copies G there behind the barrier.
+SPSP_HD void fit2_publish_rotation(FitShared& s, Fit2Shared& x, int p, float v) {
+    const int e = p - kPrmR, k = e / 9, rc = e - 9 * k, r = rc / 3, c = rc - 3 * r;
+    s.Mt[k * 16 + c * 4 + r] = v;          // Mt[k][c] = (R[0][c], R[1][c], R[2][c], 0)
+    s.Tt[k * 16 + r * 4 + c] = v;          // Tt[k][r] = (R[r][0], R[r][1], R[r][2], Jrel[r])
+    if (e >= 9) { const int j = e - 9, q = j / 13; x.pf[q * 16 + (j - 13 * q)] = v; }
+}
+
+// before fit2_init (a barrier between them): the pads of pf (chunk 15's 13th feature is P5's zero row)
+SPSP_HD void fit2_init0(Fit2Shared& x, int lane) { x.pf[lane] = 0.f; }
+// after fit_init (and a barrier): ownership, the d(beta) coefficients in LDS, the operands of the initial rotations
+SPSP_HD void fit2_init(FitShared& s, Fit2Shared& x, FitLane& r, int lane, const float* fitc, uint32_t param_mask) {
+    const int p = fit2_owned_param(lane);
+    r.trainable = p >= 0 ? (int)fit_trainable(param_mask, p) : 0;
+    for (int i = lane; i < 10 * 96; i += kFitLanes) x.cC[i] = fitc[kFcC + (i / 96) * kCPitch + (i % 96)];
+    if (lane < 12) x.beta4[lane] = lane < 10 ? s.prm[kPrmBeta + lane] : 0.f;
+    if (lane < 216) fit2_publish_rotation(s, x, lane + kPrmR, s.prm[lane + kPrmR]);
+}
+
+// P1 of v2: fit_p1 + the operands that depend on J (P2's share of them) + the root rotation
+SPSP_HD void fit2_p1(FitShared& s, const Fit2Shared& x, const FitLane& r, int lane) {
+    const F4 b0 = ld4(x.beta4), b1 = ld4(x.beta4 + 4), b2 = ld4(x.beta4 + 8);
+    const float b[10] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y};
+    if (lane < 144) {
+        float acc = r.cJ[0];
+        SPSP_UNROLL
+        for (int i = 0; i < 10; ++i) acc = fmaf(r.cJ[1 + i], b[i], acc);
+        if (lane < 72) {
+            s.J[lane] = acc;
+            if (lane < 3) s.W[lane * 4 + 3] = acc;                // W_0 = [G | J_0]
+        } else {
+            const int o = lane - 72, k = o / 3, i = o - 3 * k;
+            s.Jrel[o] = acc;
+            s.Mt[k * 16 + 12 + i] = acc;                          // Mt[k][3] = (Jrel_k, 1)
+            s.Tt[k * 16 + i * 4 + 3] = acc;                       // Tt[k][i] = (row i of R_k, Jrel_k[i])
+        }
+    } else if (lane < 153) {                                      // W_0 = [G | J_0]: the rotation the last step left in prm
+        const int e = lane - 144;
+        s.W[(e / 3) * 4 + e % 3] = s.prm[kPrmR + e];
+    }
+    const int q = lane >> 4;
+    float acc = 0.f;
+    if (lane >= 240) {
+        acc = r.cJ[0];
+        SPSP_UNROLL
+        for (int i = 0; i < 10; ++i) acc = fmaf(r.cJ[1 + i], b[i], acc);
+    }
+    const F4 r0 = ld4(x.pf + q * 16), r1 = ld4(x.pf + q * 16 + 4), r2 = ld4(x.pf + q * 16 + 8), r3 = ld4(x.pf + q * 16 + 12);
+    const float Rv[13] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+    SPSP_UNROLL
+    for (int t = 0; t < 13; ++t) acc = fmaf(r.cP[t], Rv[t], acc);
+    s.part[(lane & 15) * 16 + q] = acc;
+}
+
+// what is left of P2: the 15 face-vertex coordinates from P1's partial sums (lanes 64..78: wave 1, beside wave 0's chain walk)
+SPSP_HD void fit2_vp(FitShared& s, int lane) {
+    const int l = lane - 64;
+    if (l < 0 || l >= 15) return;
+    const float* p = s.part + l * 16;
+    const F4 a = ld4(p), b = ld4(p + 4), c = ld4(p + 8), d = ld4(p + 12);
+    s.vp[l] = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+}
+
+// torch.optim.Adam step of the lane's own parameter p from gradient g (fit_p12's statements), published where it is read
+SPSP_HD void fit2_adam(FitShared& s, Fit2Shared& x, FitLane& r, int p, float g, float w1, float b2, float w2, float eps, float step_size,
+                       float bc2_sqrt, float* param_hist_row) {
+    const float cur = s.prm[p];
+    if (param_hist_row) param_hist_row[p] = cur;                  // the iterate this iteration evaluated
+    if (s.take_best) s.best[p] = cur;
+    if (!r.trainable) return;
+    r.m = r.m + w1 * (g - r.m);
+    r.v = r.v * b2 + (w2 * g) * g;
+    const float denom = sqrtf(r.v) / bc2_sqrt + eps;
+    const float nv = cur + ((-step_size) * r.m) / denom;
+    s.prm[p] = nv;
+    if (p >= kPrmBeta) x.beta4[p - kPrmBeta] = nv;
+    else if (p >= kPrmR) fit2_publish_rotation(s, x, p, nv);
+}
+
+// P6 of v2: TWO lanes per fit joint (lane = 2 joint + coordinate; 34 lanes) -- the 17-lane form above spends ~1000 cycles of
+// wave 0 on two coordinates one after the other.  The sums that run over both coordinates (loss, l2, d loss / d scale) are the
+// SAME fma chains: the x lane's link goes to the y lane (its neighbour: DPP row_shr 1 on the GPU, the caller's array on the host),
+// which finishes the chain and writes the joint's partials.  fit2_p6a: everything up to this lane's links; fit2_p6b: the rest.
+struct Fit2P6 { float loss, l2, gs; };
+SPSP_HD int fit2_src(int joint) {                                // SPSP_FIT_SRC, five bits per fit joint
+    constexpr int t[17] = SPSP_FIT_SRC;
+    constexpr uint64_t lo = (uint64_t)t[0] | (uint64_t)t[1] << 5 | (uint64_t)t[2] << 10 | (uint64_t)t[3] << 15 | (uint64_t)t[4] << 20 |
+                            (uint64_t)t[5] << 25 | (uint64_t)t[6] << 30 | (uint64_t)t[7] << 35 | (uint64_t)t[8] << 40 |
+                            (uint64_t)t[9] << 45 | (uint64_t)t[10] << 50 | (uint64_t)t[11] << 55;
+    constexpr uint64_t hi = (uint64_t)t[12] | (uint64_t)t[13] << 5 | (uint64_t)t[14] << 10 | (uint64_t)t[15] << 15 | (uint64_t)t[16] << 20;
+    return (int)((joint < 12 ? lo >> (5 * joint) : hi >> (5 * (joint - 12))) & 31u);
+}
+// lane < 34.  Returns this lane's links of the three chains (started at 0); d, dp, gu, Xt are handed to fit2_p6b.
+SPSP_HD Fit2P6 fit2_p6a(FitShared& s, int lane, const FitParams& P, float& d_out, float& dp_out, float& gu_out, float& xt_out) {
+    const int joint = lane >> 1, c = lane & 1;
+    const int src = fit2_src(joint);
+    float X;
+    if (src < 24) X = s.W[src * 12 + 3 + 4 * c];
+    else {
+        const float* p = s.part + ((src - 24) * 3 + c) * 16;
+        const F4 a = ld4(p), b = ld4(p + 4), cc = ld4(p + 8);
+        X = ((a.x + a.y) + (a.z + a.w)) + (((b.x + b.y) + (b.z + b.w)) + ((cc.x + cc.y) + (cc.z + cc.w)));
+    }
+    const float sc = s.prm[0];
+    uint32_t lw_bits;
+    memcpy(&lw_bits, &P.loss_wh, 4);
+    const bool lw_pow2 = (lw_bits & 0x807fffffu) == 0 && lw_bits >= 0x20000000u && lw_bits <= 0x5f000000u;
+    const float lw_inv = 1.0f / P.loss_wh;
+    const float half = P.img_wh / 2.0f;
+    const float dn_du = (2.0f * half) / P.loss_wh;
+    const float coef = (2.0f * P.weight) / 34.0f;
+    const float t = s.prm[1 + c];
+    const float u = sc * (X + t);
+    const float px = (u + 1.f) * half;
+    const float y = s.tgt_px[joint * 2 + c];
+    float n, ns;
+    if (lw_pow2) { n = (2.0f * px) * lw_inv - 1.0f; ns = (2.0f * y) * lw_inv - 1.0f; }
+    else { n = (2.0f * px) / P.loss_wh - 1.0f; ns = (2.0f * y) / P.loss_wh - 1.0f; }
+    const float d = n - ns;
+    const float dp = px - y;
+    const float gu = coef * d * dn_du;                       // dL/du
+    const float gx = gu * sc;                                // dL/dX_c
+    s.g[joint * 2 + c] = gx;
+    if (src < 24) s.ga[src * 3 + c] = gx;                    // seeds of the reverse sweep
+    else s.h[(src - 24) * 3 + c] = gx;
+    s.rpart[joint * 5 + 3 + c] = gx;                         // gt[c]
+    d_out = d; dp_out = dp; gu_out = gu; xt_out = X + t;
+    return Fit2P6{fmaf(d, d, 0.f), fmaf(dp, dp, 0.f), fmaf(gu, X + t, 0.f)};
+}
+// the y lane (lane & 1) finishes the joint's chains on the x lane's links
+SPSP_HD void fit2_p6b(FitShared& s, int lane, const Fit2P6& x_link, float d, float dp, float gu, float xt) {
+    if (!(lane & 1)) return;
+    float* rp = s.rpart + (lane >> 1) * 5;
+    rp[0] = fmaf(d, d, x_link.loss);
+    rp[1] = sqrtf(fmaf(dp, dp, x_link.l2));
+    rp[2] = fmaf(gu, xt, x_link.gs);
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ void fit2_p6(FitShared& s, int lane, const FitParams& P) {     // wave 0
+    float d = 0.f, dp = 0.f, gu = 0.f, xt = 0.f;
+    Fit2P6 q{0.f, 0.f, 0.f};
+    if (lane < 34) q = fit2_p6a(s, lane, P, d, dp, gu, xt);
+    Fit2P6 prev;                                             // lane l <- lane l - 1 (DPP row_shr 1: pairs never straddle a row of 16)
+    prev.loss = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q.loss), 0x111, 0xf, 0xf, false));
+    prev.l2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q.l2), 0x111, 0xf, 0xf, false));
+    prev.gs = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q.gs), 0x111, 0xf, 0xf, false));
+    if (lane < 34) fit2_p6b(s, lane, prev, d, dp, gu, xt);
+}
+#endif
+
+// P10 of v2 in two pieces.  fit2_dj: the total dJ -- all that wave 3's d(beta) sums wait for.  fit2_dr: the rotation gradient,
+// behind the barrier, which STAYS IN THE LANE's register: its Adam step (fit2_step)
+// follows at once, beside wave 3's d(beta) sums instead of in front of them (the first form of v2 stepped in front: stamps
+// showed the ~800 cycles of an Adam step -- a square root and two IEEE divisions on a lone wave -- twice on the critical path,
+// once for the rotations and once for the betas).
+SPSP_HD void fit2_dj_item(FitShared& s, int item, int wp_off) {      // dJ_total[k][l], item = 3 k + l  (fit_p10's statements)
+    const float* const AB = s.Afin;
+    float* f = fit_f(s);
+    const int k = item / 3, l = item % 3;
+    const float* A = AB + k * 12 + 3;
+    float acc = s.dJ[item];
+    if (k == 0) acc += A[4 * l];
+    else {
+        const float* Wp = f + wp_off;
+        acc = fmaf(Wp[l], A[0], fmaf(Wp[4 + l], A[4], fmaf(Wp[8 + l], A[8], acc)));
+    }
+    const float* Wk = s.W + k * 12;
+    const float c0 = A[0] - s.adir[k * 3], c1 = A[4] - s.adir[k * 3 + 1], c2 = A[8] - s.adir[k * 3 + 2];
+    acc -= fmaf(Wk[l], c0, fmaf(Wk[4 + l], c1, Wk[8 + l] * c2));
+    s.adj[15 + item] = acc;
+}
+// ... as a short phase of its own on lanes 0..71 (item = lane).  Measured in round 4: run by wave 0 right behind its reverse walk
+// instead (two passes, no barrier pair) the iteration got 200 cycles LONGER -- the walk's wave is the critical one.
+SPSP_HD void fit2_dj(FitShared& s, const FitLane& r, int lane) {
+    if (lane >= 72) return;
+    uint32_t role2 = r.role2;
+    SPSP_OPAQUE(role2);
+    fit2_dj_item(s, lane, (int)((role2 >> 10) & 1023));
+}
+SPSP_HD float fit2_dr(FitShared& s, const FitLane& r, int lane) {
+    const float* const AB = s.Afin;
+    float* f = fit_f(s);
+    uint32_t role2 = r.role2;
+    SPSP_OPAQUE(role2);
+    float acc = 0.f;
+    if (lane < 216) {                                        // item (k, l, c): dR_k[l][c]  (fit_p10's statements)
+        const int k = lane / 9, e = lane % 9, l = e / 3, c = e % 3;
+        if (k == 0) acc = AB[l * 4 + c];
+        else {
+            const float* Wp = f + (role2 & 1023);
+            const float* A = AB + k * 12 + c;
+            acc = Wp[l] * A[0];
+            acc = fmaf(Wp[4 + l], A[4], acc);
+            acc = fmaf(Wp[8 + l], A[8], acc);
+            const F4 d0 = ld4(s.dvp), d1 = ld4(s.dvp + 4), d2 = ld4(s.dvp + 8), d3 = ld4(s.dvp + 12);
+            const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+            SPSP_UNROLL
+            for (int o = 0; o < 15; ++o) acc = fmaf(r.cQ[o], dv[o], acc);
+        }
+        s.grad[kPrmR + lane] = acc;                              // (kept for the host emulation's gradient read-out)
+    }
+    return acc;
+}
+
+// P11, wave 3 only (lanes 192..255): lane 192 + 16 g + i: the partial sums of beta_i over chunks 4 g .. 4 g + 3 of the adjoint
+// vector (fit_p11's statements per chunk); the betas' lanes (219..228, the same wave) sum them in fit2_step.
+SPSP_HD void fit2_p11a(FitShared& s, const Fit2Shared& x, int lane) {
+    const int l = lane - 192;
+    if (l < 0) return;
+    const int i = l & 15, g = l >> 4;
+    if (i >= 10) return;
+    const float* C = x.cC + i * 96 + g * 24;
+    const float* A = s.adj + g * 24;
+    F4 c[6], a[6];
+    SPSP_UNROLL
+    for (int u = 0; u < 6; ++u) { c[u] = ld4(C + 4 * u); a[u] = ld4(A + 4 * u); }
+    const float cf[24] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w, c[2].x, c[2].y, c[2].z, c[2].w,
+                          c[3].x, c[3].y, c[3].z, c[3].w, c[4].x, c[4].y, c[4].z, c[4].w, c[5].x, c[5].y, c[5].z, c[5].w};
+    const float af[24] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w, a[2].x, a[2].y, a[2].z, a[2].w,
+                          a[3].x, a[3].y, a[3].z, a[3].w, a[4].x, a[4].y, a[4].z, a[4].w, a[5].x, a[5].y, a[5].z, a[5].w};
+    float o[4];
+    SPSP_UNROLL
+    for (int u = 0; u < 4; ++u) {
+        float acc = 0.f;
+        SPSP_UNROLL
+        for (int t = 0; t < 6; ++t) acc = fmaf(cf[u * 6 + t], af[u * 6 + t], acc);
+        o[u] = acc;
+    }
+    st4(s.part + i * 16 + g * 4, o[0], o[1], o[2], o[3]);
+}
+// The Adam step of every parameter, in its owner's lane: rotation entries from the register gradient of fit2_p10, the camera from
+// P7's reductions, the betas (wave 3, behind fit2_p11a and a wave-local hand-off) from the 16 partial sums in fit_p12's order.
+SPSP_HD void fit2_step(FitShared& s, Fit2Shared& x, FitLane& r, int lane, float g_rot, float w1, float b2, float w2, float eps,
+                       float step_size, float bc2_sqrt, float* param_hist_row) {
+    const int p = fit2_owned_param(lane);
+    if (p < 0) return;
+    float g = g_rot;
+    if (p < kPrmR) g = s.red[2 + p];
+    else if (p >= kPrmBeta) {
+        const float* pp = s.part + (p - kPrmBeta) * 16;
+        const F4 a = ld4(pp), b = ld4(pp + 4), c = ld4(pp + 8), d = ld4(pp + 12);
+        g = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    }
+    fit2_adam(s, x, r, p, g, w1, b2, w2, eps, step_size, bc2_sqrt, param_hist_row);
 }
 
 }  // namespace spsp

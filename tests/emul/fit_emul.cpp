@@ -30,10 +30,26 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
     P.log_var = (float)(-std::log(loss_weight + 1e-6));
     P.weight = std::exp(-P.log_var);
     P.select_mode = select_mode; P.num_levels = num_levels;
-    std::vector<FitShared> sv(1);
+    std::vector<FitShared> sv(2);
     FitShared& s = sv[0];
+    // the v2 schedule of the product kernel (fit_core.hpp "round 4", fit.hip fit_kernel2) runs beside the phases it
+    // re-arranges, on a state of its own; after every iteration all 229 parameters must agree BIT FOR BIT
+    FitShared& s2 = sv[1];
+    std::vector<Fit2Shared> xv(1);
+    Fit2Shared& x2 = xv[0];
+    std::vector<float> lh2(iters > 0 ? iters : 1), eh2(iters > 0 ? iters : 1);
     for (int b = 0; b < B; ++b) {
         FitLane r[kFitLanes];
+        std::vector<FitLane> r2v(kFitLanes);
+        FitLane* r2 = r2v.data();
+        const bool v2 = h.walk_ok;
+        if (v2) {
+            float* Rb2 = R + (size_t)b * 216; float* bb2 = betas + (size_t)b * 10; float* cb2 = cam + (size_t)b * 3;
+            ALL_LANES(fit_init(s2, r2[lane], lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb2, bb2,
+                               cb2, joints2d + (size_t)b * 34, param_mask, h.walk));
+            ALL_LANES(fit2_init0(x2, lane));
+            ALL_LANES(fit2_init(s2, x2, r2[lane], lane, fitc, param_mask));
+        }
         float* Rb = R + (size_t)b * 216; float* bb = betas + (size_t)b * 10; float* cb = cam + (size_t)b * 3;
         ALL_LANES(fit_init(s, r[lane], lane, fitc, parents, level_joints, level_start, child_start, child_list, Rb, bb,
                            cb, joints2d + (size_t)b * 34, param_mask, h.walk_ok ? h.walk : nullptr));
@@ -79,6 +95,31 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
                          : [&] { float t = 0.f; for (int q = 0; q < 16; ++q) t += s.part[(p - kPrmBeta) * 16 + q]; return t; }();
             }
             ALL_LANES(fit_p12(s, r[lane], lane, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt));
+            if (v2) {
+                const float w1 = (float)(1.0 - beta1), b2f = (float)beta2, w2 = (float)(1.0 - beta2), epsf = (float)eps;
+                ALL_LANES(fit2_p1(s2, x2, r2[lane], lane));
+                fit_chain_walk_host(s2, h.walk);                             // wave 0 ...
+                ALL_LANES(fit2_vp(s2, lane));                                // ... beside wave 1
+                ALL_LANES(fit_p4(s2, r2[lane], lane));
+                {   // P6 on two lanes per joint: the x lane's links of the three fma chains go to the y lane (DPP on the GPU)
+                    Fit2P6 q[34];
+                    float d[34], dp[34], gu[34], xt[34];
+                    for (int lane = 0; lane < 34; ++lane) q[lane] = fit2_p6a(s2, lane, P, d[lane], dp[lane], gu[lane], xt[lane]);
+                    for (int lane = 1; lane < 34; lane += 2) fit2_p6b(s2, lane, q[lane - 1], d[lane], dp[lane], gu[lane], xt[lane]);
+                }
+                ALL_LANES(fit_p7(s2, r2[lane], lane));
+                fit_reverse_walk_host(s2, h.walk, h.walk_nb);                // wave 0 ...
+                for (int lane = 64; lane < 128; ++lane) fit_p8(s2, lane - 64, P, it, lh2.data(), eh2.data());   // ... beside wave 1
+                ALL_LANES(fit2_dj(s2, r2[lane], lane));
+                float g_rot[kFitLanes];
+                for (int lane = 192; lane < 256; ++lane) fit2_p11a(s2, x2, lane);                               // wave 3, in front of its gradients and steps
+                ALL_LANES(g_rot[lane] = fit2_dr(s2, r2[lane], lane));
+                ALL_LANES(fit2_step(s2, x2, r2[lane], lane, g_rot[lane], w1, b2f, w2, epsf, step_size, bc2_sqrt, nullptr));
+                if (std::memcmp(s.prm, s2.prm, sizeof(float) * kNumPrm) != 0) return -4;
+                if (std::memcmp(s.best, s2.best, sizeof(float) * kNumPrm) != 0) return -5;
+                if (lh && std::memcmp(&lh[it], &lh2[it], sizeof(float)) != 0) return -6;
+                if (eh && std::memcmp(&eh[it], &eh2[it], sizeof(float)) != 0) return -7;
+            }
         }
         const float* src = (select_mode == SPSP_FIT_SELECT_BEST_L2E) ? s.best : s.prm;
         for (int p = 0; p < kNumPrm; ++p) {

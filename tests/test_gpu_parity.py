@@ -339,6 +339,38 @@ def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, mon
     assert not torch.equal(runs[1][0], torch.from_numpy(R).to(dev))         # (the fit did move the pose)
 
 
+def test_fit_schedule_v2_is_bit_identical_to_the_ten_barrier_schedule(smpl_gpu, dev, monkeypatch):
+    """csrc/fit.hip fit_kernel2 (the default since round 4: eight barriers per iteration, Adam steps in the lanes that compute the
+    gradients, waves 1 and 3 working beside wave 0's tree walks -- csrc/fit_core.hpp "round 4") against the schedule of rounds 1-3
+    (`SPSP_FIT_SCHEDULE=1`, read at every launch).  The same operations produce every value in the same order: every iterate of
+    both fit variants and both select modes, the loss / l2e histories and the results, 9 players over 50 iterations, bit for bit."""
+    from soccerplayershapepose_amd.player_recon import fit_players
+    B = 9
+    R, b, cam = S.pose_params(B, seed=91, body_deg=25, global_deg=40)
+    out = smpl_gpu(body_pose=torch.from_numpy(R[:, 1:]).to(dev), global_orient=torch.from_numpy(R[:, :1]).to(dev), betas=torch.from_numpy(b).to(dev))
+    tgt = S.fit_targets_from_joints(out.joints.cpu().numpy(), cam * np.array([1.1, 1, 1], np.float32), seed=6)
+    runs = {}
+    for sched in ('2', '1'):
+        if sched == '1':
+            monkeypatch.setenv('SPSP_FIT_SCHEDULE', '1')
+        else:
+            monkeypatch.delenv('SPSP_FIT_SCHEDULE', raising=False)
+        for variant in (0, 1):
+            for select in (_abi.FIT_SELECT_LAST, _abi.FIT_SELECT_BEST_L2E):
+                Rg, bg, cg = (torch.from_numpy(a).to(dev).contiguous() for a in (R, b, cam))
+                hist = fit_players(smpl_gpu, Rg, bg, cg, tgt, variant=variant, iters=50, return_trajectory=True, select_mode=select)
+                torch.cuda.synchronize()
+                runs[(sched, variant, select)] = [Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist]
+    monkeypatch.delenv('SPSP_FIT_SCHEDULE', raising=False)
+    for variant in (0, 1):
+        for select in (_abi.FIT_SELECT_LAST, _abi.FIT_SELECT_BEST_L2E):
+            new, old = runs[('2', variant, select)], runs[('1', variant, select)]
+            assert len(new) == len(old) == 6
+            for x, y in zip(new, old):
+                assert torch.isfinite(x).all() and torch.equal(x, y)
+    assert not torch.equal(runs[('2', 1, _abi.FIT_SELECT_LAST)][0], torch.from_numpy(R).to(dev))
+
+
 # ---------------------------------------------------------------- silhouette term and the reference's exact best-iterate rule (8f-4, a11)
 def test_silhouette_render_and_metric_against_restated_neural_renderer(smpl_gpu, smpl_model_np, dev):
     """csrc/silhouette.hip vs oracle/silhouette.py (neural_renderer's projection + silhouette rasterisation restated):

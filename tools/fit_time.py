@@ -1,4 +1,5 @@
-"""Duration of the 50-iteration pose+shape fit of 32 / 22 players, alone on the GPU: tree walks against the level sweeps."""
+"""Duration of the 50-iteration pose+shape fit of 32 / 22 players, alone on the GPU: the v2 schedule (default) against the
+ten-barrier schedule of rounds 1-3 with the tree walks and with the level sweeps."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,10 +8,13 @@ from soccerplayershapepose_amd import synthetic as S
 from soccerplayershapepose_amd.models.smpl_official import SMPL
 from soccerplayershapepose_amd.player_recon import fit_players
 dev = torch.device('cuda', 0)
-for plan in ('walks', 'level sweeps'):
+for plan in ('v2', 'walks', 'level sweeps'):
     os.environ.pop('SPSP_FIT_LEVEL_SWEEPS', None)
+    os.environ.pop('SPSP_FIT_SCHEDULE', None)
     if plan == 'level sweeps':
         os.environ['SPSP_FIT_LEVEL_SWEEPS'] = '1'
+    if plan == 'walks':
+        os.environ['SPSP_FIT_SCHEDULE'] = '1'
     for B in (32, 22):
         smpl = SMPL(S.smpl_model(seed=0), max_batch=32).to(dev)
         R, b, cam = S.pose_params(B, seed=1)
