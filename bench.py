@@ -58,6 +58,9 @@ def parse(argv=None):
                     help='backbone storage / MFMA element type.  f16 (default): the mode whose vertices stay within the '
                          'north-star 1e-3 m of the all-fp32 CPU path; bf16: same bytes and MFMA rate, ~1.5e-3 m')
     ap.add_argument('--no-alt-precision', action='store_true', help='skip the second (other element type) throughput figure')
+    ap.add_argument('--tail-group', type=int, default=2,
+                    help='also report the throughput with the latency-bound tail (IEF -> fit -> SMPL) run once per this many consecutive '
+                         'batches of a slot (the convolutions keep their batch; PlayerPipeline.submit_group); 1 = skip')
     ap.add_argument('--from-detections', action='store_true',
                     help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
     ap.add_argument('--rehearse-dist', action='store_true',
@@ -551,6 +554,52 @@ def main():
         alt = {'dtype': alt_prec, 'value': world * B * args.steps / el2, 'ms_per_step': 1e3 * el2 / args.steps,
                'pre_fit_vertices': pre2, 'post_fit_vertices': out2.vertices.clone()}
 
+    # ---- the same steps with ONE tail per `--tail-group` consecutive batches of a slot (a third figure, not `value`): every batch
+    # still runs the backbone's batch-32 launches; IEF -> fit -> SMPL run once over the group's players (latency-bound chains of
+    # small launches: as long for 64 players as for 32), so a slot spends half as long per batch with no convolution in flight
+    grouped = None
+    G = max(1, args.tail_group)
+    if G > 1 and not use_dist and not args.from_detections and args.steps % G == 0:
+        if 'fres' in dir():
+            del fres
+        torch.cuda.synchronize()
+        mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=G * B, precision=args.precision).load_state_dict(sd)
+        mk_s = lambda: SMPL(model, max_batch=G * B)
+        pipe3 = PlayerPipeline(mk_r, mk_s, dev, depth=max(1, args.depth), streams=[sl.stream for sl in pipe.slots])
+        gstate = SimpleNamespace(i=0)
+
+        def gstep():
+            ks = [(gstate.i * G + j) % n_inputs for j in range(G)]
+            gstate.i += 1
+            return ks, pipe3.submit_group([inputs[k].native for k in ks], [inputs[k].tgt for k in ks], fit=args.fit, iters=FIT_ITERS)
+        ks0, r0 = gstep()
+        torch.cuda.synchronize()
+        # every player of the group bit-identical to the per-batch path
+        same = True
+        for k, one in zip(ks0, r0):
+            ref_ = reconstruct_players(reg, smpl, inputs[k].native, inputs[k].tgt, fit=args.fit, iters=FIT_ITERS)
+            torch.cuda.synchronize()
+            same = same and all(torch.equal(getattr(one, f), getattr(ref_, f)) for f in ('cam', 'rotmats', 'betas', 'vertices', 'joints', 'translation'))
+        if args.graphs:
+            import math
+            pipe3.use_graphs = True
+            for _ in range(math.lcm(len(pipe3.slots), max(1, n_inputs // math.gcd(n_inputs, G)))):
+                gstep()
+            torch.cuda.synchronize()
+        for _ in range(max(1, args.warmup // G)):
+            gstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps // G):
+            gstep()
+        torch.cuda.synchronize()
+        el3 = time.perf_counter() - t0
+        grouped = {'batches_per_tail': G, 'value': world * B * args.steps / el3, 'unit': 'players/s', 'ms_per_step': 1e3 * el3 / args.steps,
+                   'bit_identical_to_per_batch_path': bool(same),
+                   'what': f'the same {args.steps} steps of {B} crops; the backbone runs batch by batch, IEF -> fit -> SMPL once per {G} consecutive '
+                           f'batches of a slot (PlayerPipeline.submit_group / spsp_pipeline_group)'}
+        del pipe3
+
     if rank == 0:
         achieved = cands[dom] / (kernels[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels else None
         achieved_iso = cands[dom] / (kernels_iso[dom]['avg_us'] * 1e-6) / 1e12
@@ -607,6 +656,8 @@ def main():
                                            'live_over_rocprof': kernels_iso[dom]['avg_us'] / rp}
         if alt is not None:
             line['alt_precision'] = {'dtype': alt['dtype'], 'value': alt['value'], 'unit': 'players/s', 'ms_per_step': alt['ms_per_step']}
+        if grouped is not None:
+            line['grouped_tail'] = grouped
         if world == 1 and not args.no_cpu_baseline:
             threads = host_threads(args.cpu_threads)
             base, parity = cpu_baseline(sd, model, torch.from_numpy(parity_input.x_nchw), parity_input.tgt_np, args.cpu_fit_sample, threads,

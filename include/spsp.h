@@ -172,6 +172,13 @@ int spsp_crop_players(spsp_ctx* ctx, const uint8_t* frame, int H, int W, const i
 /* forward: proxy -> cam [B,3], pose6d [B,144], betas [B,10]; feats [B,512] optional (NULL to skip). */
 int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B,
                            float* cam, float* pose6d, float* betas, float* feats, void* stream);
+/* The two halves of spsp_regressor_forward on their own (it is exactly backbone(..., 0) + ief):
+ *   backbone: proxy crops -> pooled features, rows [feat_row, feat_row + B) of the handle's feature buffer (max_batch rows);
+ *   ief:      the iterative-error-feedback MLP on rows [0, B) of that buffer -> cam / pose6d / betas (feats optional).
+ * Several backbone calls with different feat_row, then ONE ief over all their rows: how spsp_pipeline_group batches the
+ * latency-bound tail of the path (IEF -> fit -> SMPL) over consecutive batches while the convolutions keep their batch. */
+int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, int feat_row, void* stream);
+int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, float* pose6d, float* betas, float* feats, void* stream);
 /* Launch plan of the handle's forwards (same results to fp32 summation order; takes effect at the next forward, not inside a
  * captured graph).  SPSP_PLAN_THROUGHPUT (default): for several batches in flight on different streams -- the kernels with the
  * least CU time per batch.  SPSP_PLAN_LATENCY: for ONE batch in flight -- layer4's convolutions on twice the workgroups (the whole
@@ -401,6 +408,15 @@ typedef struct {
 int spsp_pipeline(spsp_ctx* ctx, spsp_regressor* regressor, spsp_smpl* smpl, spsp_relate* relate, const void* proxy,
                   int proxy_format, const float* boxes, const float* joints2d, const spsp_fit_config* fit, int B,
                   float focal, float resolution, const spsp_pipeline_out* out, void* stream);
+/* The same path for `ngroups` consecutive batches of B crops each with ONE tail: the backbone runs batch by batch (the launches
+ * of spsp_pipeline at batch B, proxies[g] -> feature rows g*B ..), then IEF -> fit -> SMPL forward run ONCE over all
+ * ngroups*B players.  Those stages are latency-bound chains of small launches (one workgroup per player in the fit) whose
+ * duration does not depend on the number of players, so a stream spends half (a third, ...) as long in them per batch; every
+ * player's results are bit-identical to spsp_pipeline's.  joints2d and every buffer of `out` hold ngroups*B players (group g at
+ * rows g*B ..); both handles need max_batch >= ngroups*B (<= 256).  No relation module in this form. */
+int spsp_pipeline_group(spsp_ctx* ctx, spsp_regressor* regressor, spsp_smpl* smpl, const void* const* proxies, int ngroups,
+                        int proxy_format, const float* joints2d, const spsp_fit_config* fit, int B, float focal,
+                        float resolution, const spsp_pipeline_out* out, void* stream);
 
 #ifdef __cplusplus
 }

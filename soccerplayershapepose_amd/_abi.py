@@ -140,12 +140,16 @@ _PROTOS = {
     'spsp_allgather_records': (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     'spsp_pipeline': (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.POINTER(FitConfig), C.c_int, C.c_float,
                                C.c_float, C.POINTER(PipelineOut), _vp]),
+    'spsp_pipeline_group': (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp), C.c_int, C.c_int, _vp, C.POINTER(FitConfig), C.c_int, C.c_float,
+                                     C.c_float, C.POINTER(PipelineOut), _vp]),
     'spsp_relate_load': (C.c_int, [_vp, C.POINTER(RelateWeights), C.c_int, C.POINTER(_vp)]),
     'spsp_relate_free': (None, [_vp]),
     'spsp_relate_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     'spsp_proxy_build': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'spsp_crop_players': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'spsp_regressor_backbone': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    'spsp_regressor_ief': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'spsp_regressor_read_stage': (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     'spsp_regressor_status': (C.c_int, [_vp]),
     'spsp_regressor_set_plan': (C.c_int, [_vp, C.c_int]),

@@ -45,4 +45,39 @@ int spsp_pipeline(spsp_ctx* ctx, spsp_regressor* regressor, spsp_smpl* smpl, sps
     return SPSP_OK;
 }
 
+int spsp_pipeline_group(spsp_ctx* ctx, spsp_regressor* regressor, spsp_smpl* smpl, const void* const* proxies, int ngroups,
+                        int proxy_format, const float* joints2d, const spsp_fit_config* fit, int B, float focal,
+                        float resolution, const spsp_pipeline_out* out, void* stream) {
+    SPSP_REQUIRE(ctx && regressor && smpl && out && proxies, "spsp_pipeline_group: NULL handle / output block");
+    SPSP_REQUIRE(B >= 0 && ngroups >= 1 && ngroups <= 8, "spsp_pipeline_group: %d groups of %d", ngroups, B);
+    if (B == 0) return SPSP_OK;
+    SPSP_REQUIRE(out->cam && out->pose6d && out->betas && out->rotmats, "spsp_pipeline_group: cam, pose6d, betas and rotmats outputs are required");
+    SPSP_REQUIRE(!fit || joints2d, "spsp_pipeline_group: a fit configuration needs joints2d");
+    const int N = ngroups * B;
+    int rc;
+#define TRY(x) do { rc = (x); if (rc != SPSP_OK) return rc; } while (0)
+    for (int g = 0; g < ngroups; ++g) {
+        SPSP_REQUIRE(proxies[g], "spsp_pipeline_group: NULL proxy batch %d", g);
+        TRY(spsp_regressor_backbone(ctx, regressor, proxies[g], proxy_format, B, g * B, stream));
+    }
+    TRY(spsp_regressor_ief(ctx, regressor, N, out->cam, out->pose6d, out->betas, nullptr, stream));
+    float* R = out->rotmats;
+    if (fit) {
+        spsp::FitEnds ends;
+        ends.pose6d = out->pose6d;
+        ends.translation = out->translation; ends.focal = focal; ends.resolution = resolution;
+        ends.record = out->record;
+        TRY(spsp::fit_launch(ctx, smpl, fit, R, out->betas, out->cam, joints2d, N, nullptr, nullptr, nullptr, ends, stream));
+    } else {
+        TRY(spsp_rot6d_to_rotmat(ctx, out->pose6d, N * 24, R, stream));
+    }
+    if (out->vertices || out->joints) TRY(spsp_smpl_forward(ctx, smpl, R, out->betas, N, out->vertices, out->joints, stream));
+    if (!fit) {
+        if (out->translation) TRY(spsp_wp_to_translation(ctx, out->cam, N, focal, resolution, out->translation, stream));
+        if (out->record) TRY(spsp_pack_record(ctx, out->cam, R, out->betas, N, out->record, stream));
+    }
+#undef TRY
+    return SPSP_OK;
+}
+
 }  // extern "C"

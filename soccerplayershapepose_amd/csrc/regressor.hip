@@ -536,17 +536,16 @@ int spsp_proxy_pack(spsp_ctx* ctx, const float* proxy_nchw, int B, int precision
     return SPSP_OK;
 }
 
-int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, float* cam,
-                           float* pose6d, float* betas, float* feats, void* stream) {
-    SPSP_REQUIRE(ctx && r, "spsp_regressor_forward: NULL handle");
+// The backbone alone: proxy crops -> pooled features, rows [feat_row, feat_row + B) of the handle's feature buffer.
+int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, int feat_row, void* stream) {
+    SPSP_REQUIRE(ctx && r, "spsp_regressor_backbone: NULL handle");
     SPSP_HIP_CHECK(hipSetDevice(ctx->device));      // a process may hold contexts on several GPUs
     SPSP_TRY(spsp_regressor_status(r));             // a device-side failure of an earlier forward surfaces on the next call
     if (B == 0) return SPSP_OK;
-    SPSP_REQUIRE(proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
-    SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_forward: B=%d exceeds max_batch=%d", B, r->max_batch);
+    SPSP_REQUIRE(proxy, "spsp_regressor_backbone: NULL argument");
+    SPSP_REQUIRE(B >= 0 && feat_row >= 0 && feat_row + B <= r->max_batch, "spsp_regressor_backbone: rows %d..%d exceed max_batch=%d", feat_row, feat_row + B, r->max_batch);
     SPSP_REQUIRE(proxy_format == SPSP_PROXY_NCHW_F32 || proxy_format == SPSP_PROXY_NATIVE,
-                 "spsp_regressor_forward: unknown proxy_format %d", proxy_format);
-    if (B == 0) return SPSP_OK;
+                 "spsp_regressor_backbone: unknown proxy_format %d", proxy_format);
     hipStream_t st = as_stream(stream);
     int rc;
 #define TRY(x) do { rc = (x); if (rc != SPSP_OK) return rc; } while (0)
@@ -555,7 +554,7 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         TRY(spsp_proxy_pack(ctx, static_cast<const float*>(proxy), B, r->f16, r->x0, stream));
         x0 = r->x0;
     }
-    // tile-scheduler counters of this forward's persistent launches
+    // tile-scheduler counters of this forward's persistent launches (and the IEF's arrival counters)
     SPSP_HIP_CHECK(hipMemsetAsync(r->counters, 0, kCounterWords * sizeof(unsigned int), st));
     r->next_counter = 0;
     // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
@@ -586,7 +585,7 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
             TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, nullptr, st, L));          // out -> bc
             ci += 3;
             TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, nullptr, st, L));         // t
-            float* pool = (L == 3) ? r->feats : nullptr;
+            float* pool = (L == 3) ? r->feats + (size_t)feat_row * kFeat : nullptr;
             TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, pool, st, L));             // out -> bb (+ avg-pool)
             ci += 2;
             x = bb;
@@ -595,14 +594,27 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
         r->stage_ptr[2 + L] = x;
     }
     r->last_B = B;
-    // IEF (ief_module.py:48-64): params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) } -- one launch
+    SPSP_HIP_CHECK(hipGetLastError());
+#undef TRY
+    return SPSP_OK;
+}
+
+// The IEF alone (ief_module.py:48-64) on rows [0, B) of the handle's feature buffer:
+// params = init; 3x { params += fc3(relu(fc2(relu(fc1([feat | params]))))) } -- one launch
+int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, float* pose6d, float* betas, float* feats, void* stream) {
+    SPSP_REQUIRE(ctx && r, "spsp_regressor_ief: NULL handle");
+    SPSP_HIP_CHECK(hipSetDevice(ctx->device));
+    if (B == 0) return SPSP_OK;
+    SPSP_REQUIRE(cam && pose6d && betas, "spsp_regressor_ief: NULL argument");
+    SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_ief: B=%d exceeds max_batch=%d", B, r->max_batch);
+    hipStream_t st = as_stream(stream);
     if (r->ief_iters > 0) {
         const int npb = (B + 31) / 32;
         IefArgs ia;
         ia.feats = r->feats; ia.w1f = r->w1f; ia.w13 = r->w13; ia.w2 = r->w2; ia.w3 = r->w3;
         ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
         ia.h1 = r->h1; ia.s = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
-        ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed above)
+        ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed by the backbone call)
         ia.B = B; ia.iters = r->ief_iters;
         ia.err = r->err_dev;
         ia.spin_limit = 1u << 22;
@@ -621,8 +633,17 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
     }
     SPSP_HIP_CHECK(hipGetLastError());
     if (feats) SPSP_HIP_CHECK(hipMemcpyAsync(feats, r->feats, (size_t)B * kFeat * sizeof(float), hipMemcpyDeviceToDevice, st));
-#undef TRY
     return SPSP_OK;
+}
+
+int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, float* cam,
+                           float* pose6d, float* betas, float* feats, void* stream) {
+    SPSP_REQUIRE(ctx && r, "spsp_regressor_forward: NULL handle");
+    if (B == 0) { SPSP_HIP_CHECK(hipSetDevice(ctx->device)); SPSP_TRY(spsp_regressor_status(r)); return SPSP_OK; }
+    SPSP_REQUIRE(proxy && cam && pose6d && betas, "spsp_regressor_forward: NULL argument");
+    SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_forward: B=%d exceeds max_batch=%d", B, r->max_batch);
+    SPSP_TRY(spsp_regressor_backbone(ctx, r, proxy, proxy_format, B, 0, stream));
+    return spsp_regressor_ief(ctx, r, B, cam, pose6d, betas, feats, stream);
 }
 
 int spsp_regressor_status(spsp_regressor* r) {

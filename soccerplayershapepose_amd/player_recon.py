@@ -413,6 +413,57 @@ def reconstruct_players(regressor, smpl, proxy_rep, joints2D, *, fit='pose_shape
     return res
 
 
+def reconstruct_players_group(regressor, smpl, proxy_reps, joints2D, *, fit='pose_shape', iters=50, lr=None,
+                              select_mode=_abi.FIT_SELECT_LAST, return_record=False):
+    """`reconstruct_players` for a GROUP of consecutive batches with one tail (`spsp_pipeline_group`): the backbone runs batch
+    by batch -- the launches of `reconstruct_players` at the batch size of `proxy_reps[i]` --, then IEF -> fit -> SMPL forward
+    run once over all the group's players.  Those stages are latency-bound chains of small launches whose duration does not
+    depend on the number of players (the fit is one workgroup per player), so a pipeline slot spends half as long in them per
+    batch; every player's results are bit-identical to `reconstruct_players`'.
+    proxy_reps: list of equally shaped batches; joints2D: list of [B,17,>=2] (one per batch) or one [G*B,17,>=2] tensor.
+    Both handles need max_batch >= G*B.  Returns one result namespace per batch: views of the group's output tensors."""
+    xs, fmt = [], None
+    for x in proxy_reps:
+        x, f = regressor.prepare_input(x)
+        if fmt is not None and (f != fmt or x.shape != xs[0].shape):
+            raise ValueError('reconstruct_players_group: the batches of a group must have one shape and layout')
+        fmt = f
+        xs.append(x)
+    G, B = len(xs), xs[0].shape[0]
+    N = G * B
+    r = rt.get(xs[0].device)
+    smpl.to(r.device)
+    if N > smpl.max_batch or N > regressor.max_batch:
+        raise ValueError(f'reconstruct_players_group: {G} x {B} players exceed a handle\'s max_batch ({regressor.max_batch} / {smpl.max_batch})')
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=r.device)
+    cam, pose6d, betas, R = f32(N, 3), f32(N, 144), f32(N, 10), f32(N, 24, 3, 3)
+    vertices, joints, translation = f32(N, 6890, 3), f32(N, 90, 3), f32(N, 3)
+    out = _abi.PipelineOut(cam=rt.ptr(cam).value, pose6d=rt.ptr(pose6d).value, betas=rt.ptr(betas).value, rotmats=rt.ptr(R).value,
+                           vertices=rt.ptr(vertices).value, joints=rt.ptr(joints).value, translation=rt.ptr(translation).value)
+    record = None
+    if return_record:
+        record = f32(N, _abi.RECORD_FLOATS)
+        out.record = rt.ptr(record).value
+    cfg = j2d = None
+    if fit is not None:
+        variant = {'camera': 0, 'pose_shape': 1}[fit]
+        cfg = _fit_config(r, variant, iters, lr, None, select_mode)
+        if isinstance(joints2D, (list, tuple)):
+            joints2D = torch.cat([rt.dev_f32(torch.as_tensor(j)[..., :2], r.device).reshape(B, 17, 2) for j in joints2D])
+        j2d = rt.dev_f32(torch.as_tensor(joints2D)[..., :2], r.device).reshape(N, 17, 2).contiguous()
+    ptrs = (C.c_void_p * G)(*[rt.ptr(x).value for x in xs])
+    r.check(r.lib.spsp_pipeline_group(r.ctx, regressor.handle, smpl.handle, ptrs, G, fmt, rt.ptr(j2d),
+                                      C.byref(cfg) if cfg is not None else None, B, config.FOCAL_LENGTH,
+                                      config.proxy_rep_input_wh, C.byref(out), r.stream()), 'spsp_pipeline_group')
+    res = []
+    for g in range(G):
+        sl = slice(g * B, (g + 1) * B)
+        res.append(SimpleNamespace(cam=cam[sl], rotmats=R[sl], betas=betas[sl], vertices=vertices[sl], joints=joints[sl],
+                                   translation=translation[sl], pose6d=pose6d[sl], record=None if record is None else record[sl],
+                                   _keep=(j2d, xs)))
+    return res
+
+
 def pack_record(cam, R, betas):
     """[cam(3) | R(216) | betas(10)] = 229 fp32 per player: the all-gather payload."""
     B = cam.shape[0]
@@ -571,6 +622,62 @@ class PlayerPipeline:
         out.stream = slot.stream
         out.hold_until = pending.append
         return _with_wait(out)
+
+    def submit_group(self, proxy_reps, joints2Ds, buffer_set=0, **kw):
+        """`submit` for a GROUP of consecutive batches on ONE slot with one tail (`reconstruct_players_group`): the backbone
+        batch by batch, IEF -> fit -> SMPL once over all the group's players.  A slot's stream then spends half (a third, ..)
+        as long per batch in those latency-bound stages, during which it has no convolution in flight -- the throughput form
+        for a caller that can hand over two batches at a time (bench.py --tail-group).  The handles need max_batch >= the
+        group's players.  Returns one result per batch (views of the group's tensors; all complete at the same event)."""
+        slot = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        caller = torch.cuda.current_stream(self.device)
+        if self.use_graphs:
+            if not caller.query():
+                caller.synchronize()                                        # (on the host in front of a graph replay: see submit)
+        else:
+            slot.stream.wait_stream(caller)
+        pending = slot.pending.setdefault(buffer_set if self.use_graphs else 0, [])
+        for ev in pending:
+            if self.use_graphs:
+                ev.synchronize()
+            else:
+                slot.stream.wait_event(ev)
+        pending.clear()
+        for t in list(proxy_reps) + list(joints2Ds):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(slot.stream)
+        with torch.cuda.stream(slot.stream):
+            if not self.use_graphs:
+                res = reconstruct_players_group(slot.regressor, slot.smpl, proxy_reps, joints2Ds, **kw)
+            else:
+                if not all(torch.is_tensor(t) and t.is_cuda for t in list(proxy_reps) + list(joints2Ds)):
+                    raise ValueError('PlayerPipeline(use_graphs=True): inputs must be device tensors (a graph replays fixed buffers)')
+                key = ('group', tuple(t.data_ptr() for t in proxy_reps), tuple(proxy_reps[0].shape), proxy_reps[0].dtype,
+                       tuple(t.data_ptr() for t in joints2Ds), tuple(sorted(kw.items())), buffer_set)
+                entry = slot.graphs.get(key)
+                if entry is None:
+                    if not slot.warm:
+                        reconstruct_players_group(slot.regressor, slot.smpl, proxy_reps, joints2Ds, **kw)
+                        slot.warm = True
+                    slot.stream.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=slot.stream):
+                        res = reconstruct_players_group(slot.regressor, slot.smpl, proxy_reps, joints2Ds, **kw)
+                    if len(slot.graphs) >= 16:
+                        slot.graphs.pop(next(iter(slot.graphs)))
+                    entry = slot.graphs[key] = (g, res, list(proxy_reps), list(joints2Ds))
+                g, res = entry[0], entry[1]
+                slot.regressor.check_status()
+                g.replay()
+            done = torch.cuda.Event()
+            done.record(slot.stream)
+        outs = []
+        for one in res:
+            o = SimpleNamespace(**vars(one))
+            o.done, o.stream, o.hold_until = done, slot.stream, pending.append
+            outs.append(_with_wait(o))
+        return outs
 
     def synchronize(self):
         for s in self.slots:

@@ -1115,6 +1115,47 @@ def test_player_pipeline_streams_and_graph_replay_are_bit_identical_to_the_seria
         PlayerPipeline(mk_r, mk_s, dev, depth=1, use_graphs=True).submit(native, tgt.cpu().numpy())
 
 
+def test_grouped_tail_is_bit_identical_to_the_per_batch_path(regressor_sd_np, smpl_model_np, dev):
+    """`spsp_pipeline_group` / `reconstruct_players_group` / `PlayerPipeline.submit_group`: the backbone batch by batch into rows
+    of the handle's feature buffer, then IEF -> fit (R built from pose6d inside the kernel) -> SMPL forward ONCE over the
+    players of two or three consecutive batches.  Every player is independent in every one of those stages, so each batch of
+    a group must equal a plain `reconstruct_players` call bit for bit -- eager, replayed from a HIP graph, for groups of 2
+    and 3, at a batch that fills whole IEF blocks (32) and one that does not (5) -- and `spsp_regressor_backbone` +
+    `spsp_regressor_ief` must equal `spsp_regressor_forward`."""
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    from soccerplayershapepose_amd.models.smpl_official import SMPL
+    from soccerplayershapepose_amd.player_recon import PlayerPipeline, reconstruct_players, reconstruct_players_group
+    fields = ('cam', 'pose6d', 'rotmats', 'betas', 'vertices', 'joints', 'translation', 'record')
+    for B, G in ((32, 2), (5, 3)):
+        mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=G * B, precision='f16').load_state_dict(regressor_sd_np)
+        mk_s = lambda: SMPL(smpl_model_np, max_batch=G * B)
+        reg, smpl = mk_r().to(dev), mk_s().to(dev)
+        x, _ = S.proxy_crops(G * B, seed=11 + B)
+        natives = [reg.pack(torch.from_numpy(x[g * B:(g + 1) * B]).to(dev)) for g in range(G)]
+        tgts = [(torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(30 + g)) * 300 + 100).to(dev) for g in range(G)]
+        refs = []
+        for g in range(G):
+            o = reconstruct_players(reg, smpl, natives[g], tgts[g], fit='pose_shape', iters=12, return_record=True)
+            torch.cuda.synchronize()
+            refs.append({f: getattr(o, f).clone() for f in fields})
+        assert (refs[0]['vertices'] - refs[1]['vertices']).abs().max().item() > 1e-4
+        got = reconstruct_players_group(reg, smpl, natives, tgts, fit='pose_shape', iters=12, return_record=True)
+        torch.cuda.synchronize()
+        for g in range(G):
+            for f in fields:
+                assert torch.equal(getattr(got[g], f), refs[g][f]), f'B={B} group of {G}: batch {g} differs in {f}'
+        for use_graphs in (False, True):
+            pipe = PlayerPipeline(mk_r, mk_s, dev, depth=2, use_graphs=use_graphs)
+            outs = [pipe.submit_group(natives, tgts, fit='pose_shape', iters=12, return_record=True) for _ in range(5)]
+            pipe.synchronize()
+            for grp in outs:
+                for g in range(G):
+                    for f in fields:
+                        assert torch.equal(getattr(grp[g], f), refs[g][f]), f'use_graphs={use_graphs} B={B}: batch {g} differs in {f}'
+        with pytest.raises(ValueError):
+            reconstruct_players_group(reg, smpl, natives + natives, tgts + tgts, fit='pose_shape', iters=2)      # more players than max_batch
+
+
 def test_player_pipeline_is_correct_next_to_kernels_on_the_callers_stream(dev, monkeypatch):
     """The hazard of round 3: with ROCm 7.2 a HIP-graph replay issued behind `hipStreamWaitEvent` on a REAL
     event of another stream -- one recorded behind a kernel, i.e. as soon as the application runs anything of its own on the

@@ -21,7 +21,7 @@ model = S.smpl_model(seed=0)
 r = rt.get(dev)
 nk = r.lib.spsp_profile_num_kernels()
 names = [r.lib.spsp_profile_kernel_name(i).decode() for i in range(nk)]
-for B in (32, 22, 8, 1):
+for B in [int(v) for v in sys.argv[2:]] or (32, 22, 8, 1):
     smpl = SMPL(model, max_batch=B).to(dev)
     R, b, cam = S.pose_params(B, seed=5 + B, body_deg=30, global_deg=60)
     Rt, bt = torch.from_numpy(R).to(dev), torch.from_numpy(b).to(dev)
