@@ -94,6 +94,8 @@ struct StemArgs {
     uint16_t* out;           // [B][66][66][64]: pooled map with a 1-px zero border (interior written here)
     int bands;               // bands per image
     int rows_per_band;       // conv rows per band: 16, 8 or 4 (a band = rows_per_band / 2 pool rows)
+    unsigned int* zero;      // words the FIRST workgroup zeroes: the tile-scheduler / hand-off counters of the forward's later kernels
+    int nzero;               //   (this is the forward's first kernel; a memset node in front of it cost ~5 us of every forward)
     unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of one workgroup
 };
 
@@ -106,6 +108,8 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0)
+        for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0u;
     SSTAMPK(0);
     const int h = wave & 1, r = wave >> 1;                    // channel half, conv row within the step
     const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
@@ -347,10 +351,11 @@ namespace spsp {
 
 // conv1 + BN + ReLU + max-pool for B crops: in = native [B][262][264][18], out = [B][66][66][64] (interior).
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     hipStream_t st) {
+                     unsigned int* zero_words, int nzero, hipStream_t st) {
     SPSP_REQUIRE(in && w && bias && out && B > 0, "conv_stem: bad arguments");
     StemArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.zero = zero_words; a.nzero = zero_words ? nzero : 0;
     // bands of 16 conv rows (8 per image) fill 256 CUs at 32 crops with one halo step in nine; smaller batches take
     // finer bands so that the grid still covers the chip
     a.rows_per_band = B * 8 >= num_cus ? 16 : (B * 16 >= num_cus ? 8 : 4);

@@ -554,13 +554,13 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
         TRY(spsp_proxy_pack(ctx, static_cast<const float*>(proxy), B, r->f16, r->x0, stream));
         x0 = r->x0;
     }
-    // tile-scheduler counters of this forward's persistent launches (and the IEF's arrival counters)
-    SPSP_HIP_CHECK(hipMemsetAsync(r->counters, 0, kCounterWords * sizeof(unsigned int), st));
+    // the tile-scheduler counters of this forward's persistent launches and the IEF's arrival counters are zeroed by the stem
+    // kernel's first workgroup (a memset node here cost ~5 us of every forward: 4 us + a launch boundary)
     r->next_counter = 0;
     // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
     {
         ProfScope ps(ctx, kKStem, st, true);
-        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, st));
+        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st));
     }
     r->stage_ptr[0] = nullptr;
     r->stage_ptr[1] = r->p1;
