@@ -21,38 +21,44 @@ namespace {
 using namespace spsp;
 
 constexpr int kSkinThreads = 256;     // the four accumulating / skinning waves
-constexpr int kChainWaves = 8;        // + one wave per player that turns its (R, betas) into the skinning transforms (two waves with four
-                                      // players each, one after the other, took as long as the blend phase: a chain is ~2.5 us of latency)
+constexpr int kChainWaves = 4;        // + four waves that turn (R, betas) of the workgroup's players into the skinning transforms, two
+                                      // players each, one after the other (a chain is ~2.5 us of dependent LDS round trips: two fit
+                                      // under the blend phase, four -- two chain waves -- do not: 27.9 instead of 22.9 us).  One wave
+                                      // PER PLAYER (12 waves, 62 KB of LDS: two workgroups per CU) is as fast alone and cost the four-slot
+                                      // pipeline 1 %: a workgroup that size finds room beside the other slots' convolutions less often
 constexpr int kSkinBlock = kSkinThreads + 64 * kChainWaves;
 constexpr int kPB = 8;   // players per skin workgroup (16 measured slower in round 3: 27.7 vs 19.0 us -- 236 VGPRs and 82 KB of LDS leave one workgroup of four waves per CU)
+constexpr int kChainPlayers = kPB / kChainWaves;
 static_assert(kPB % kChainWaves == 0, "players split evenly over the chain waves");
 
-// Per chain wave: one player's rotation matrices / joints / world transforms.
+// Per chain wave: its players' rotation matrices and betas (fetched before the workgroup's first barrier) and one player's joints.
 struct ChainLds {
-    float R[216], beta[16], J[72], W[288];
+    float R[kChainPlayers][216], beta[kChainPlayers][16], J[72];
 };
 
 // One wavefront, one player: J = Jbar + JS . betas, the level-parallel kinematic chain, A_k = [W_k.R | W_k.t - W_k.R J_k]
 // (smplx batch_rigid_transform); the posed joints 0..23 are W_k.t.  Until round 4 this was a kernel of its own (one wavefront
 // per player, 10.6 us + a launch boundary in front of the skin kernel -- part of the serial tail every pipeline slot waits
-// for); now eight extra waves of every skin workgroup run it, one player each, WHILE the other four stream the blend
-// basis.  Same statements in the same order as before: bit-identical transforms.  Everything it reads from global memory
-// (R, betas, the joint constants, the tree) is fetched BEFORE the workgroup's first barrier: a dependent global round trip
-// behind the blend loop's loads takes microseconds (first version: the skin kernel 19.5 -> 29 us, as long as both kernels).
-__device__ __forceinline__ void chain_one_player(ChainLds& c, const float* sJc, const TreeLds& tree, float* A_lds, float* A_out,
-                                                 float* joints_out, int lane) {
-    joints_from_betas(sJc, sJc + 72, c.beta, c.J, lane);
+// for); now four extra waves of every skin workgroup run it for the workgroup's players WHILE the other four stream the blend
+// basis.  Same statements in the same order as before: bit-identical transforms.  The world transforms are built IN the
+// player's slot of sA (same 3 x 4 layout) and only their translation column is rewritten at the end.  Everything read from
+// global memory (R, betas, the joint constants, the tree) is fetched BEFORE the workgroup's first barrier: a dependent global
+// round trip behind the blend loop's loads takes microseconds (first version: the skin kernel 19.5 -> 29 us).
+__device__ __forceinline__ void chain_one_player(const float* Rm, const float* beta, float* J, const float* sJc, const TreeLds& tree,
+                                                 float* A_lds, float* A_out, float* joints_out, int lane) {
+    joints_from_betas(sJc, sJc + 72, beta, J, lane);
     lds_phase_sync<true>();
-    chain_forward<true>(c.R, c.J, c.W, tree, lane);
+    chain_forward<true>(Rm, J, A_lds, tree, lane);
     for (int o = lane; o < 72; o += 64) {
         const int k = o / 3, i = o % 3;
-        const float* w = c.W + k * 12 + i * 4;
-        const float t = w[3] - (w[0] * c.J[k * 3] + w[1] * c.J[k * 3 + 1] + w[2] * c.J[k * 3 + 2]);
-        float* a = A_lds + k * 12 + i * 4;
-        a[0] = w[0]; a[1] = w[1]; a[2] = w[2]; a[3] = t;
+        float* w = A_lds + k * 12 + i * 4;
+        const float w3 = w[3];
+        const float t = w3 - (w[0] * J[k * 3] + w[1] * J[k * 3 + 1] + w[2] * J[k * 3 + 2]);
+        w[3] = t;
         if (A_out) { float* g = A_out + k * 12 + i * 4; g[0] = w[0]; g[1] = w[1]; g[2] = w[2]; g[3] = t; }
-        if (joints_out) joints_out[k * 3 + i] = w[3];
+        if (joints_out) joints_out[k * 3 + i] = w3;
     }
+    lds_phase_sync<true>();                                // (J is reused by the wave's next player)
 }
 
 // Workgroup = 4 waves over the SAME 64 vertices and kPB players: wave w accumulates rows [55w, 55w+55) of the
@@ -80,21 +86,28 @@ __global__ __launch_bounds__(kSkinBlock) void smpl_skin_kernel(const float* __re
     const int b0 = grp * kPB;
     const int nb = min(kPB, B - b0);
     if (ks >= 4) {
-        static_assert(kChainWaves == kPB, "one chain wave per player");
         ChainLds& c = sChain[ks - 4];
-        const int p = ks - 4;
-        const size_t b = b0 + (p < nb ? p : 0);
         if (ks == 4) load_tree(sTree, parents, level_joints, level_start, num_levels, lane);
         for (int i = threadIdx.x - kSkinThreads; i < 792; i += 64 * kChainWaves) sJc[i] = jconst[i];
-        for (int i = lane; i < 216; i += 64) c.R[i] = R[b * 216 + i];
-        if (lane < 10) c.beta[lane] = betas[b * 10 + lane];
+#pragma unroll
+        for (int q = 0; q < kChainPlayers; ++q) {
+            const int p = (ks - 4) * kChainPlayers + q;
+            const size_t b = b0 + (p < nb ? p : 0);
+            for (int i = lane; i < 216; i += 64) c.R[q][i] = R[b * 216 + i];
+            if (lane < 10) c.beta[q][lane] = betas[b * 10 + lane];
+        }
         __syncthreads();                                   // (the staging barrier of the other waves)
         const bool first = vtile == 0;
-        if (p < nb)
-            chain_one_player(c, sJc, sTree, &sA[p][0], first ? A_ws + b * 288 : nullptr,
-                             (first && joints_out) ? joints_out + b * SPSP_NUM_OUT_JOINTS * 3 : nullptr, lane);
-        else
-            for (int i = lane; i < 288; i += 64) sA[p][i] = 0.f;
+        for (int q = 0; q < kChainPlayers; ++q) {
+            const int p = (ks - 4) * kChainPlayers + q;
+            if (p < nb) {
+                const size_t b = b0 + p;
+                chain_one_player(c.R[q], c.beta[q], c.J, sJc, sTree, &sA[p][0], first ? A_ws + b * 288 : nullptr,
+                                 (first && joints_out) ? joints_out + b * SPSP_NUM_OUT_JOINTS * 3 : nullptr, lane);
+            } else {
+                for (int i = lane; i < 288; i += 64) sA[p][i] = 0.f;
+            }
+        }
         __syncthreads();                                   // (the barrier in front of the skinning: sA is complete)
         return;
     }
