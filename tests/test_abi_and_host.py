@@ -51,7 +51,7 @@ def test_profile_kernel_names_and_native_layout_size():
     lib = _abi.load()
     n = lib.spsp_profile_num_kernels()
     names = [lib.spsp_profile_kernel_name(i).decode() for i in range(n)]
-    assert 'fit_kernel' in names and len(set(names)) == n
+    assert 'fit_kernel2' in names and len(set(names)) == n
     assert lib.spsp_proxy_native_bytes() == 262 * 264 * 18 * 2
     # roofline candidates (every launch does the same algorithmic work) are MFMA convolutions of the default plan or fallbacks
     cands = [names[i] for i in range(n) if lib.spsp_profile_kernel_flop_per_crop(i) > 0]
