@@ -201,6 +201,7 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_PLAN_LAYER4_CHANNELS 3
 #define SPSP_DEBUG_PLAN_PATCH 4
 #define SPSP_DEBUG_PLAN_PATCH_PRODUCER 5   /* value = layer (1..3) * 10 + (0 | 1): four DMA-only producer waves in that stage's patch kernel */
+#define SPSP_DEBUG_PLAN_P4 7               /* bit L set: the 3x3 stride-1 convs of layer L+1 on conv_p4.hip (256-pixel tiles, no K split, producer waves); default: bit 1 = layer2 */
 #define SPSP_DEBUG_PLAN_S2RS 6             /* 0: layer2.0's stride-2 pair on the streaming kernel of the other stages, 1 (default): weights stationary in registers */
 int spsp_regressor_debug(spsp_regressor* r, int what, int value);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`

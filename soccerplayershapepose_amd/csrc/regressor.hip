@@ -306,6 +306,11 @@ struct spsp_regressor {
     int ief_capacity = 0;               // IEF workgroups the device can hold at once (occupancy x CUs)
     int debug_ief_stall = 0;
     bool use_s2 = true;                 // stride-2 stages on conv_s2.hip (experiment builds: SPSP_NO_S2 = the ring kernel of round 2)
+    // bit L: the 3x3 / 1 convs of residual stage L on conv_p4.hip (256-pixel tiles, no K split, producer waves).  layer2 always
+    // (256 workgroups at B = 32: 13.1 -> 11.7 us per launch).  layer3 = one image per workgroup, 128 workgroups at B = 32: 12.0 ->
+    // 14.9 us with one batch in flight, but 40 % less CU time -- the four-slot pipeline gains 1.6-1.9 % (tools/ab_pipeline.py):
+    // plan "throughput" only
+    int p4_layers = 6;
     bool use_s2rs = true;               // layer2.0 on conv_s2rs.hip (weights stationary in registers); off: conv_s2.hip like the other two
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
@@ -343,6 +348,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
         return launch_conv_wres(a, ctx->num_cus, st);
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
+        if (((r->p4_layers >> L) & 1) && conv_p4_supported(a)) {       // layer2; layer3 in plan "throughput": no K split, producer waves
+            ProfScope ps(ctx, kKConvP4, st, true);
+            return launch_conv_p4(a, st);
+        }
         ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
         return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], r->patch_nch[L],
                                  r->patch_prod[L] && r->patch_tile[L] == 128 && r->patch_ring[L] == 3 && r->patch_db[L], st);
@@ -507,6 +516,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
             for (int L = 0; L < 4; ++L) if (d[L] >= 0 && d[L] < (int)kRingNone) r->ring[L] = (RingTile)d[L];
         }
         if (getenv("SPSP_NO_S2")) r->use_s2 = false;
+        if (const char* e = getenv("SPSP_P4")) r->p4_layers = atoi(e) & 6;
         if (const char* e = getenv("SPSP_PATCH_DB")) {
             int d[4] = {0, 0, 1, 1};
             (void)sscanf(e, "%d,%d,%d,%d", &d[0], &d[1], &d[2], &d[3]);
@@ -661,6 +671,7 @@ int spsp_regressor_set_plan(spsp_regressor* r, int plan) {
     SPSP_REQUIRE(r, "spsp_regressor_set_plan: NULL handle");
     SPSP_REQUIRE(plan == SPSP_PLAN_THROUGHPUT || plan == SPSP_PLAN_LATENCY, "spsp_regressor_set_plan: unknown plan %d", plan);
     r->patch_nch[3] = plan == SPSP_PLAN_LATENCY ? 32 : 64;
+    r->p4_layers = plan == SPSP_PLAN_LATENCY ? 2 : 6;
     return SPSP_OK;
 }
 
@@ -670,6 +681,7 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
         case SPSP_DEBUG_IEF_STALL: r->debug_ief_stall = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)
         case SPSP_DEBUG_PLAN_LAYER4_CHANNELS:
             SPSP_REQUIRE(value == 32 || value == 64, "spsp_regressor_debug: layer4 blocks of %d channels", value);
             r->patch_nch[3] = value;

@@ -310,6 +310,40 @@ def test_layer2_stride2_pair_with_register_stationary_weights_is_bit_identical(d
                 assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
+    """csrc/conv_p4.hip: the 3x3 / 1 convolutions of layer2 (both plans) and layer3 (plan "throughput") on 256-pixel tiles with
+    four accumulating waves over the whole K and four producer waves (`SPSP_DEBUG_PLAN_P4`, bit L = residual stage L; 0 =
+    conv_patch.hip everywhere: K split over wave pairs, halves added through LDS).  The same products, added in another order
+    (and starting from the bias instead of adding it last): layer2's and layer3's feature maps within 1.5e-3 (f16) / 1e-2 (bf16)
+    of the map's largest value, the regressor outputs within 1e-4 / 1e-3; B = 32 and 22 (XCD-aware and plain tile order), 8, 3
+    (grids below one workgroup per CU).  The default plan (stages against the rounding-emulating oracle, tests above) runs this
+    kernel; this test keeps conv_patch.hip's layer2 / layer3 forms covered and pins the two against each other."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec, tol_map, tol_out in (('f16', 1.5e-3, 1e-4), ('bf16', 1e-2, 1e-3)):
+        for B in (32, 22, 8, 3):
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=90 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = {}
+            for plan in (0, 2, 6):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_P4, plan), 'debug')
+                out = [t.clone() for t in reg(native)]
+                maps = [reg.read_stage(s, B).clone() for s in (3, 4)]
+                torch.cuda.synchronize()
+                reg.check_status()
+                got[plan] = (out, maps)
+            for plan in (2, 6):
+                for a, b in zip(got[plan][0], got[0][0]):
+                    assert torch.isfinite(a).all() and float((a - b).abs().max()) <= tol_out
+                for a, b in zip(got[plan][1], got[0][1]):
+                    assert float((a - b).abs().max()) <= tol_map * float(b.abs().max())
+            # plan 2 leaves layer3 on conv_patch.hip: given the same layer2 map, plan 6's layer2 map is plan 2's bit for bit
+            assert torch.equal(got[2][1][0], got[6][1][0])
+
+
 def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, monkeypatch):
     """The fit's kinematic chain and reverse sweep run as register-resident walks over quads of lanes (csrc/fit_core.hpp:
     fit_chain_walk, fit_reverse_walk_a / _b -- DPP row broadcasts in place of eight LDS hand-offs per sweep); the level sweeps

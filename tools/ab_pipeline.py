@@ -29,14 +29,20 @@ def patch(L, tile, ring, db):
 
 
 prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in layers]
+base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)]
 PLANS = {
-    's2 + layer4 64ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
-    's2 + layer4 64ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)] + prod(2, 3),
-    's2 + layer4 64ch + producer waves in layer3': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)] + prod(2),
-    's2 + layer4 32ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)] + prod(2, 3),
-    's2 + layer4 32ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)],
-    's2 + 64ch + producers in layer3 / layer4 + layer2 as 128 px tiles with producers': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 3, 1)] + prod(1, 2, 3),
+    'layer2 / layer3 on conv_patch (K split over wave pairs)': base + [(_abi.DEBUG_PLAN_P4, 0)],
+    'layer2 on conv_p4 (no K split, producer waves)': base + [(_abi.DEBUG_PLAN_P4, 2)],
+    'layer2 + layer3 on conv_p4 (layer3: one image per workgroup, 128 workgroups)': base + [(_abi.DEBUG_PLAN_P4, 6)],
+    'layer3 on conv_p4': base + [(_abi.DEBUG_PLAN_P4, 4)],
 }
+if os.environ.get('AB_OLD_PLANS'):
+    PLANS = {
+        's2 + layer4 64ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
+        's2 + layer4 64ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)] + prod(2, 3),
+        's2 + layer4 32ch + producer waves in layer3 / layer4': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 32)] + prod(2, 3),
+        's2 + 64ch + producers in layer3 / layer4 + layer2 as 128 px tiles with producers': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), patch(1, 128, 3, 1)] + prod(1, 2, 3),
+    }
 streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
 x, _ = S.proxy_crops(B, seed=1234)
 tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(3)) * 300 + 100).to(dev)
