@@ -407,15 +407,28 @@ def main():
     # ---- untimed per-kernel pass: every kernel bracketed by a HIP-event pair on its launch stream, ONE batch in
     # flight (slot 0, a sync after every step), so a launch's duration is free of the cross-batch sharing the
     # pipelined timed region has by design (and agrees with the rocprofv3 average of the same command)
+    # -- in plan "latency", the plan FOR one batch in flight (every grid fills the chip): a launch's duration against the chip's
+    # peak says how good the kernel is.  The pipeline's slots run plan "throughput" (narrow persistent grids: layer1 on a quarter
+    # of the CUs ...), whose launches take longer alone by design; their isolated durations are reported beside
+    # (kernels_isolated_throughput_plan_*), the pipelined region itself by roofline.end_to_end_backbone_frac.
     iso_steps = 2 * n_inputs
-    r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
-    r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
-    for _ in range(iso_steps):
+
+    def isolated_pass(plan):
+        reg.set_plan(plan)
         pipe._next = 0
         step()
         torch.cuda.synchronize()
-    r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
-    kernels_iso = read_profile(iso_steps)
+        r.check(r.lib.spsp_profile_select(r.ctx, -1), 'spsp_profile_select')
+        r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
+        for _ in range(iso_steps):
+            pipe._next = 0
+            step()
+            torch.cuda.synchronize()
+        r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
+        return read_profile(iso_steps)
+    kernels_iso_tp = isolated_pass('throughput')
+    kernels_iso = isolated_pass('latency')
+    reg.set_plan('throughput')
     pipe._next = 0
     # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all do the same
     # algorithmic work (the library names it: spsp_profile_kernel_flop_per_crop > 0)
@@ -625,7 +638,7 @@ def main():
             # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's
             # event pair also spans the time its workgroups share CUs with other batches' kernels; that figure is
             # kept as *_timed_region.
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved_iso, 'peak': MFMA_PEAK_TFLOPS,
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'plan': 'latency', 'achieved': achieved_iso, 'peak': MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved_iso / MFMA_PEAK_TFLOPS,
                          'traffic': traffic,
                          'avg_us': kernels_iso[dom]['avg_us'],
@@ -644,8 +657,10 @@ def main():
             'latency': {'workload': f'one {FRAME_PLAYERS}-player match frame (BASELINE configs[3]) through the whole path, nothing else in '
                                     f'flight (regressor plan "latency"' + (', one HIP-graph replay' if args.graphs else '') + f'), {world} GPU(s)' + (', players sharded 3,3,... + all-gather' if world > 1 else ''),
                         'ms': frame_latency_ms},
+            'kernels_isolated_plan': 'latency (one batch in flight: chip-filling grids)',
             'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},
+            'kernels_isolated_throughput_plan_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso_tp.items()},
         }
         # cross-check against the TRACKED rocprofv3 kernel trace of the isolated command (same build): the live figure must be
         # reproducible from a file under profiles/

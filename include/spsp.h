@@ -179,10 +179,13 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
  * latency-bound tail of the path (IEF -> fit -> SMPL) over consecutive batches while the convolutions keep their batch. */
 int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, int feat_row, void* stream);
 int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, float* pose6d, float* betas, float* feats, void* stream);
-/* Launch plan of the handle's forwards (same results to fp32 summation order; takes effect at the next forward, not inside a
- * captured graph).  SPSP_PLAN_THROUGHPUT (default): for several batches in flight on different streams -- the kernels with the
- * least CU time per batch.  SPSP_PLAN_LATENCY: for ONE batch in flight -- layer4's convolutions on twice the workgroups (the whole
- * chip instead of half of it): shorter launches, more staging traffic. */
+/* Launch plan of the handle's forwards (same results up to the fp32 summation order of layer3; takes effect at the next forward,
+ * not inside a captured graph).
+ * SPSP_PLAN_LATENCY (a fresh handle's plan): for ONE batch in flight -- every kernel's grid fills the chip.
+ * SPSP_PLAN_THROUGHPUT: for several batches in flight on different streams (four pipeline slots) -- the kernels with the least CU
+ * time per batch: the persistent kernels run NARROW (layer1 on a quarter of the CUs with eight tiles per resident weight set,
+ * the stem in bands of 64 rows), layer3 one image per workgroup without the K split (conv_p4.hip, half the chip), layer4 in
+ * 64-channel blocks (half the chip).  One batch alone takes ~0.2 ms longer this way; four in flight finish 6-8 % more players/s. */
 #define SPSP_PLAN_THROUGHPUT 0
 #define SPSP_PLAN_LATENCY    1
 int spsp_regressor_set_plan(spsp_regressor* r, int plan);
@@ -201,6 +204,8 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_PLAN_LAYER4_CHANNELS 3
 #define SPSP_DEBUG_PLAN_PATCH 4
 #define SPSP_DEBUG_PLAN_PATCH_PRODUCER 5   /* value = layer (1..3) * 10 + (0 | 1): four DMA-only producer waves in that stage's patch kernel */
+#define SPSP_DEBUG_PLAN_STEM_BAND 9        /* conv rows per workgroup of the stem kernel (0: grid-filling default, 32, 64, 128 = one workgroup per crop) */
+#define SPSP_DEBUG_PLAN_WRES_CUS 8         /* layer1's persistent workgroups on 1 / value of the CUs (1, 2, 4, 8, 16): more tiles per resident weight set */
 #define SPSP_DEBUG_PLAN_P4 7               /* bit L set: the 3x3 stride-1 convs of layer L+1 on conv_p4.hip (256-pixel tiles, no K split, producer waves); default: bit 1 = layer2 */
 #define SPSP_DEBUG_PLAN_S2RS 6             /* 0: layer2.0's stride-2 pair on the streaming kernel of the other stages, 1 (default): weights stationary in registers */
 int spsp_regressor_debug(spsp_regressor* r, int what, int value);

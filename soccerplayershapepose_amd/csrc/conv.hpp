@@ -73,6 +73,6 @@ int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);
 // conv_stem.hip: conv1 + BN + ReLU + max-pool in one kernel: native input [B][262][264][18] -> pooled map [B][66][66][64];
 // its first workgroup also zeroes `nzero` words at `zero_words` (the counters of the forward's later kernels; may be NULL)
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t stream);
+                     unsigned int* zero_words, int nzero, hipStream_t stream, int rows_per_band = 0);
 
 }  // namespace spsp

@@ -351,14 +351,19 @@ namespace spsp {
 
 // conv1 + BN + ReLU + max-pool for B crops: in = native [B][262][264][18], out = [B][66][66][64] (interior).
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t st) {
+                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band) {
     SPSP_REQUIRE(in && w && bias && out && B > 0, "conv_stem: bad arguments");
+    SPSP_REQUIRE(rows_per_band == 0 || (rows_per_band >= 4 && rows_per_band <= 128 && (rows_per_band & (rows_per_band - 1)) == 0),
+                 "conv_stem: bands of %d conv rows (a power of two, 4 .. 128)", rows_per_band);
     StemArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.zero = zero_words; a.nzero = zero_words ? nzero : 0;
     // bands of 16 conv rows (8 per image) fill 256 CUs at 32 crops with one halo step in nine; smaller batches take
     // finer bands so that the grid still covers the chip
     a.rows_per_band = B * 8 >= num_cus ? 16 : (B * 16 >= num_cus ? 8 : 4);
+    // (plan "throughput": coarser bands = fewer, longer-lived workgroups -- the 114 KB of weights and the halo step are paid per band)
+    // -- as long as a quarter of the chip still has a workgroup each
+    while (a.rows_per_band < rows_per_band && B * (128 / (2 * a.rows_per_band)) * 4 >= num_cus) a.rows_per_band *= 2;
     a.bands = 128 / a.rows_per_band;
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<false>>(kLds));
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<true>>(kLds));

@@ -310,7 +310,16 @@ struct spsp_regressor {
     // (256 workgroups at B = 32: 13.1 -> 11.7 us per launch).  layer3 = one image per workgroup, 128 workgroups at B = 32: 12.0 ->
     // 14.9 us with one batch in flight, but 40 % less CU time -- the four-slot pipeline gains 1.6-1.9 % (tools/ab_pipeline.py):
     // plan "throughput" only
-    int p4_layers = 6;
+    int p4_layers = 2;
+    // Plan "throughput": with four batches in flight on four streams a kernel that fills the chip for a short time competes with
+    // three others for every CU, and pays its prologue (layer1: 72 KB of weights + the first patch per workgroup, a third of its
+    // run time at two tiles per workgroup) once per workgroup.  Persistent kernels are therefore launched NARROW there: layer1 on a
+    // quarter of the CUs (8 tiles per resident weight set), the stem in bands of 64 conv rows (64 workgroups at B = 32).  Four-slot
+    // pipeline, same box: 120.8 k -> 127.6 k players/s with layer1 on 1/4 (1/8: 124.3 k, 1/16: 106.9 k), 128.6 k with the stem bands
+    // as well (bands of 128 rows = 32 workgroups: 110.9 k) -- tools/ab_pipeline.py, profiles/r04_ab_narrow.txt.  One batch in flight
+    // pays for it (layer1 61 -> ~240 us): plan "latency" keeps the chip-filling grids.
+    int stem_band = 0;                  // conv rows per stem workgroup when coarser than the grid-filling default (32, 64, 128: the whole image)
+    int wres_cu_div = 1;                // layer1's persistent workgroups: num_cus / this (2: twice the tiles per workgroup, half the chip)
     bool use_s2rs = true;               // layer2.0 on conv_s2rs.hip (weights stationary in registers); off: conv_s2.hip like the other two
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
@@ -345,7 +354,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     if (conv_wres_supported(a)) {                      // layer1: 3x3 / 1, 64 -> 64, weights resident in LDS
         ++r->next_counter;
         ProfScope ps(ctx, kKConvWres, st, true);
-        return launch_conv_wres(a, ctx->num_cus, st);
+        return launch_conv_wres(a, ctx->num_cus / r->wres_cu_div, st);
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
         if (((r->p4_layers >> L) & 1) && conv_p4_supported(a)) {       // layer2; layer3 in plan "throughput": no K split, producer waves
@@ -501,7 +510,8 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // launch consumes, and 256 workgroups of 32 channels stage the input patch twice as often (A/B in one process,
         // tools/ab_pipeline.py: 116.0 k vs 113.4 k players/s); a single batch in flight finishes sooner on 256 workgroups
         // (18.9 -> 13.2 us per launch, tools/ab_plan.py): spsp_regressor_set_plan(SPSP_PLAN_LATENCY)
-        const int def_nch[4] = {64, 64, 64, 64};
+        // (a fresh handle is in plan "latency": spsp_regressor_set_plan)
+        const int def_nch[4] = {64, 64, 64, 32};
         // layer3 / layer4 (128-pixel tiles, four accumulating waves): four DMA-only producer waves per workgroup (conv_patch.hip,
         // PROD) -- layer4's launch 18.2 -> 15.5 us (64-channel blocks), 13.0 -> 12.6 (32), layer3's 12.7 -> 12.1, bit-identical
         // results (tools/ab_plan.py, run g3aa); in the four-slot pipeline the gain is within the noise (+0.4 %, tools/ab_pipeline.py)
@@ -570,7 +580,7 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
     // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
     {
         ProfScope ps(ctx, kKStem, st, true);
-        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st));
+        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st, r->stem_band));
     }
     r->stage_ptr[0] = nullptr;
     r->stage_ptr[1] = r->p1;
@@ -672,6 +682,8 @@ int spsp_regressor_set_plan(spsp_regressor* r, int plan) {
     SPSP_REQUIRE(plan == SPSP_PLAN_THROUGHPUT || plan == SPSP_PLAN_LATENCY, "spsp_regressor_set_plan: unknown plan %d", plan);
     r->patch_nch[3] = plan == SPSP_PLAN_LATENCY ? 32 : 64;
     r->p4_layers = plan == SPSP_PLAN_LATENCY ? 2 : 6;
+    r->wres_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 4;
+    r->stem_band = plan == SPSP_PLAN_LATENCY ? 0 : 64;
     return SPSP_OK;
 }
 
@@ -682,6 +694,14 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)
+        case SPSP_DEBUG_PLAN_WRES_CUS:
+            SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8 || value == 16, "spsp_regressor_debug: layer1 on 1 / %d of the CUs", value);
+            r->wres_cu_div = value;
+            return SPSP_OK;
+        case SPSP_DEBUG_PLAN_STEM_BAND:
+            SPSP_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64 || value == 128, "spsp_regressor_debug: stem bands of %d rows", value);
+            r->stem_band = value;
+            return SPSP_OK;
         case SPSP_DEBUG_PLAN_LAYER4_CHANNELS:
             SPSP_REQUIRE(value == 32 || value == 64, "spsp_regressor_debug: layer4 blocks of %d channels", value);
             r->patch_nch[3] = value;

@@ -23,13 +23,14 @@ def _np(a):
 
 class SingleInputRegressor:
     def __init__(self, resnet_in_channels=18, resnet_layers=18, ief_iters=3, mean_params=None, max_batch=32,
-                 precision='f16', plan='throughput'):
+                 precision='f16', plan='latency'):
         if resnet_in_channels != 18 or resnet_layers != 18:
             raise NotImplementedError('only the configuration the reference ever instantiates is built: '
                                       'SingleInputRegressor(18, 18, 3) (PR/player_recon.py:134-136)')
         self.ief_iters = ief_iters
         self.max_batch = max_batch
-        # launch plan (include/spsp.h): 'throughput' for several batches in flight (PlayerPipeline), 'latency' for one
+        # launch plan (include/spsp.h): 'latency' (default) for one batch in flight -- chip-filling grids; 'throughput' for several
+        # batches in flight on different streams (PlayerPipeline selects it for its slots): narrow persistent grids, least CU time
         if plan not in ('throughput', 'latency'):
             raise ValueError(f"plan must be 'throughput' or 'latency', got {plan!r}")
         self.plan = plan

@@ -513,9 +513,11 @@ class PlayerPipeline:
     underneath the MFMA-bound backbone of batch i+1.  Every batch still goes through the complete path; results
     are returned with the event that marks their completion."""
 
-    def __init__(self, make_regressor, make_smpl, device, depth=2, use_graphs=False, streams=None):
+    def __init__(self, make_regressor, make_smpl, device, depth=2, use_graphs=False, streams=None, plan='auto'):
         """`streams`: run on these HIP streams (one per slot) instead of new ones -- a second pipeline of a process
-        should take over an idle pipeline's streams: past four active hardware queues the GPU time-slices them."""
+        should take over an idle pipeline's streams: past four active hardware queues the GPU time-slices them.
+        `plan`: the regressor launch plan of the slots' handles ('auto': 'throughput' for two or more slots -- several batches
+        in flight --, 'latency' for one; None: whatever make_regressor chose)."""
         self.device = torch.device(device)
         self.use_graphs = bool(use_graphs)
         self.slots = []
@@ -525,6 +527,8 @@ class PlayerPipeline:
             st = streams[i] if streams is not None else torch.cuda.Stream(device=self.device)
             self.slots.append(SimpleNamespace(stream=st, regressor=make_regressor().to(self.device),
                                               smpl=make_smpl().to(self.device), done=None, graphs={}, warm=False, pending={}))
+            if plan is not None:
+                self.slots[-1].regressor.set_plan(('throughput' if depth >= 2 else 'latency') if plan == 'auto' else plan)
         self._next = 0
         self._nudge_in, self._nudge_keep = None, None
 

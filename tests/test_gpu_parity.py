@@ -315,14 +315,14 @@ def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
     four accumulating waves over the whole K and four producer waves (`SPSP_DEBUG_PLAN_P4`, bit L = residual stage L; 0 =
     conv_patch.hip everywhere: K split over wave pairs, halves added through LDS).  The same products, added in another order
     (and starting from the bias instead of adding it last): layer2's and layer3's feature maps within 1.5e-3 (f16) / 1e-2 (bf16)
-    of the map's largest value, the regressor outputs within 1e-4 / 1e-3; B = 32 and 22 (XCD-aware and plain tile order), 8, 3
+    of the map's largest value, the regressor outputs within 1e-4 / 1e-3; B = 32 and 22 (XCD-aware and plain tile order), 8 and 3
     (grids below one workgroup per CU).  The default plan (stages against the rounding-emulating oracle, tests above) runs this
     kernel; this test keeps conv_patch.hip's layer2 / layer3 forms covered and pins the two against each other."""
     from soccerplayershapepose_amd import runtime as rt
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
     sd = S.regressor_state_dict(seed=0)
-    for prec, tol_map, tol_out in (('f16', 1.5e-3, 1e-4), ('bf16', 1e-2, 1e-3)):
-        for B in (32, 22, 8, 3):
+    for prec, tol_map, tol_out, batches in (('f16', 1.5e-3, 1e-4, (32, 22, 3)), ('bf16', 1e-2, 1e-3, (32, 8))):
+        for B in batches:
             reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
             r = rt.get(dev)
             x, _ = S.proxy_crops(B, seed=90 + B)
@@ -342,6 +342,40 @@ def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
                     assert float((a - b).abs().max()) <= tol_map * float(b.abs().max())
             # plan 2 leaves layer3 on conv_patch.hip: given the same layer2 map, plan 6's layer2 map is plan 2's bit for bit
             assert torch.equal(got[2][1][0], got[6][1][0])
+
+
+def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
+    """Plan "throughput" launches the persistent kernels narrow -- layer1 (conv_wres.hip) on a quarter of the CUs, the stem
+    (conv_stem.hip) in bands of up to 64 conv rows -- and plan "latency" chip-filling (`SPSP_DEBUG_PLAN_WRES_CUS`,
+    `SPSP_DEBUG_PLAN_STEM_BAND`).  Which workgroup computes a tile changes, nothing about the tile: the pooled stem map, layer1's
+    map and the regressor outputs are equal bit for bit at B = 32 (64-row bands), 22 (32-row bands) and 3, both element types;
+    and the two named plans differ only by layer3's summation order (conv_p4.hip against conv_patch.hip)."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec, batches in (('f16', (32, 22, 3)), ('bf16', (32,))):
+        for B in batches:
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=40 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = []
+            for div, band in ((1, 0), (4, 64), (2, 32), (16, 128)):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_WRES_CUS, div), 'debug')
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM_BAND, band), 'debug')
+                out = [t.clone() for t in reg(native)] + [reg.read_stage(s_, B).clone() for s_ in (1, 2)]
+                torch.cuda.synchronize()
+                reg.check_status()
+                got.append(out)
+            for other in got[1:]:
+                for a, b in zip(got[0], other):
+                    assert torch.isfinite(a).all() and torch.equal(a, b)
+            if B == 32:
+                lat = [t.clone() for t in reg.set_plan('latency')(native)] + [reg.read_stage(3, B).clone()]
+                thr = [t.clone() for t in reg.set_plan('throughput')(native)] + [reg.read_stage(3, B).clone()]
+                torch.cuda.synchronize()
+                assert torch.equal(lat[-1], thr[-1])                      # up to layer2 the plans run the same arithmetic
+                assert all(float((a - b).abs().max()) <= (1e-4 if prec == 'f16' else 1e-3) for a, b in zip(lat[:-1], thr[:-1]))
 
 
 def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, monkeypatch):
@@ -1125,7 +1159,7 @@ def test_player_pipeline_streams_and_graph_replay_are_bit_identical_to_the_seria
     x, _ = S.proxy_crops(2 * B, seed=5)
     xa, xb = torch.from_numpy(x[:B]).to(dev), torch.from_numpy(x[B:]).to(dev)
     tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(3)) * 300 + 100).to(dev)
-    ref_reg, ref_smpl = mk_r().to(dev), mk_s().to(dev)
+    ref_reg, ref_smpl = mk_r().to(dev).set_plan('throughput'), mk_s().to(dev)      # (the plan PlayerPipeline selects for its slots)
     native = ref_reg.pack(xa)
     ref_a = reconstruct_players(ref_reg, ref_smpl, native, tgt, fit='pose_shape', iters=10)
     va, ca = ref_a.vertices.clone(), ref_a.cam.clone()
@@ -1163,7 +1197,7 @@ def test_grouped_tail_is_bit_identical_to_the_per_batch_path(regressor_sd_np, sm
     for B, G in ((32, 2), (5, 3)):
         mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=G * B, precision='f16').load_state_dict(regressor_sd_np)
         mk_s = lambda: SMPL(smpl_model_np, max_batch=G * B)
-        reg, smpl = mk_r().to(dev), mk_s().to(dev)
+        reg, smpl = mk_r().to(dev).set_plan('throughput'), mk_s().to(dev)
         x, _ = S.proxy_crops(G * B, seed=11 + B)
         natives = [reg.pack(torch.from_numpy(x[g * B:(g + 1) * B]).to(dev)) for g in range(G)]
         tgts = [(torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(30 + g)) * 300 + 100).to(dev) for g in range(G)]
@@ -1207,7 +1241,7 @@ def test_player_pipeline_is_correct_next_to_kernels_on_the_callers_stream(dev, m
     sd, model = S.regressor_state_dict(seed=0), S.smpl_model(seed=0)
     mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(sd).to(dev)
     mk_s = lambda: SMPL(model, max_batch=B)
-    ref_reg, ref_smpl = mk_r(), mk_s().to(dev)
+    ref_reg, ref_smpl = mk_r().set_plan('throughput'), mk_s().to(dev)
     inputs, refs = [], []
     for k in range(4):
         x, _ = S.proxy_crops(B, seed=900 + k)
@@ -1248,7 +1282,7 @@ def test_player_pipeline_keeps_freshly_allocated_inputs_alive_across_streams(reg
     mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B).load_state_dict(regressor_sd_np)
     mk_s = lambda: SMPL(smpl_model_np, max_batch=B)
     x, _ = S.proxy_crops(3 * B, seed=21)
-    ref_reg, ref_smpl = mk_r().to(dev), mk_s().to(dev)
+    ref_reg, ref_smpl = mk_r().to(dev).set_plan('throughput'), mk_s().to(dev)      # (the plan PlayerPipeline selects for its slots)
     natives = [ref_reg.pack(torch.from_numpy(x[i * B:(i + 1) * B]).to(dev)) for i in range(3)]
     tgts = [(torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(30 + i)) * 300 + 100).to(dev) for i in range(3)]
     refs = [reconstruct_players(ref_reg, ref_smpl, natives[i], tgts[i], fit='pose_shape', iters=10).vertices.clone() for i in range(3)]

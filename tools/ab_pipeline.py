@@ -29,12 +29,17 @@ def patch(L, tile, ring, db):
 
 
 prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in layers]
-base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)]
+base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), (_abi.DEBUG_PLAN_P4, 6)]
+W, SB = _abi.DEBUG_PLAN_WRES_CUS, _abi.DEBUG_PLAN_STEM_BAND
 PLANS = {
-    'layer2 / layer3 on conv_patch (K split over wave pairs)': base + [(_abi.DEBUG_PLAN_P4, 0)],
-    'layer2 on conv_p4 (no K split, producer waves)': base + [(_abi.DEBUG_PLAN_P4, 2)],
-    'layer2 + layer3 on conv_p4 (layer3: one image per workgroup, 128 workgroups)': base + [(_abi.DEBUG_PLAN_P4, 6)],
-    'layer3 on conv_p4': base + [(_abi.DEBUG_PLAN_P4, 4)],
+    'conv_p4, layer1 on all CUs, stem bands 16': base + [(W, 1)],
+    'layer1 on 1/4': base + [(W, 4)],
+    'layer1 on 1/8': base + [(W, 8)],
+    'layer1 on 1/16': base + [(W, 16)],
+    'layer1 on 1/4, stem bands 32': base + [(W, 4), (SB, 32)],
+    'layer1 on 1/4, stem bands 64': base + [(W, 4), (SB, 64)],
+    'layer1 on 1/4, stem bands 128': base + [(W, 4), (SB, 128)],
+    'layer1 on 1/8, stem bands 64': base + [(W, 8), (SB, 64)],
 }
 if os.environ.get('AB_OLD_PLANS'):
     PLANS = {
