@@ -54,7 +54,7 @@ int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels = 64
 // conv_p4.hip: the same convolutions on 256-pixel tiles without the split of K over wave pairs: four accumulating waves over
 // the whole K + four producer waves (layer2)
 bool conv_p4_supported(const ConvArgs& a);
-int launch_conv_p4(const ConvArgs& a, hipStream_t stream);
+int launch_conv_p4(const ConvArgs& a, int max_workgroups, hipStream_t stream);      // fewer workgroups than tiles: persistent
 
 // conv_s2.hip: the 3x3 stride-2 conv of a residual stage with the stage's 1x1 stride-2 downsample riding on it (w2 / bias2 /
 // out2 / n2), on an LDS-resident patch split into the four parity planes of the input; 128 output pixels x 64 channels per workgroup

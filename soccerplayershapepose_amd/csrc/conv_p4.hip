@@ -87,62 +87,87 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
     const int w = wave_id & 3;                                     // consumer: pixel rows 4 w .. 4 w + 3; producer: its share of the pieces
     const int W = a.Wo;
     const int mt = a.M / 256, nb = a.N / 64;
-    int m_tile, n_blk;
-    {   // XCD-aware tile order, as conv_patch.hip
-        const int XN = a.xcd_n, XM = XN > 0 ? 8 / XN : 0;
-        const int bid = blockIdx.x;
-        if (XN > 0 && mt % XM == 0 && nb % XN == 0) {
-            const int x = bid & 7, li = bid >> 3, nbl = nb / XN;
-            m_tile = (x / XN) * (mt / XM) + li / nbl;
-            n_blk = ((x % XN) * nbl + li % nbl) * 64;
-        } else {
-            m_tile = bid / nb;
-            n_blk = (bid % nb) * 64;
-        }
-    }
     const int tpr = W / 16, tpi = tpr * tpr;
-    const int img0 = m_tile / tpi;
-    const int tt = m_tile - img0 * tpi;
-    const int y0 = (tt / tpr) * 16, x0 = (tt % tpr) * 16;
     const int nchunks = a.chunks, ngroups = 3 * nchunks;
     const int Ktot = a.nsteps * 64;
     const int drow = lane >> 3, dchunk = lane & 7;
+    // PERSISTENT over tiles blockIdx.x + i * gridDim.x (plan "throughput" launches fewer workgroups than tiles: the DMA stream
+    // runs on across the tile boundary -- the next tile's first patch and groups land under this tile's last taps and epilogue,
+    // so only a workgroup's FIRST tile pays the ~5 k cycles of L2 -> LDS time before the first MFMA)
+    const int nwg = gridDim.x;
+    const int ntiles = (mt * nb - (int)blockIdx.x + nwg - 1) / nwg;
+    struct Tile { int img0, y0, x0, n_blk; };
+    auto tile_of = [&](int i) {
+        const int v = blockIdx.x + i * nwg;
+        int m_tile, n_blk;
+        // XCD-aware tile order, as conv_patch.hip (gridDim.x is a multiple of 8 whenever it is below the tile count: v & 7 = the XCD)
+        const int XN = a.xcd_n, XM = XN > 0 ? 8 / XN : 0;
+        if (XN > 0 && mt % XM == 0 && nb % XN == 0) {
+            const int x = v & 7, li = v >> 3, nbl = nb / XN;
+            m_tile = (x / XN) * (mt / XM) + li / nbl;
+            n_blk = ((x % XN) * nbl + li % nbl) * 64;
+        } else {
+            m_tile = v / nb;
+            n_blk = (v % nb) * 64;
+        }
+        const int img0 = m_tile / tpi, tt = m_tile - img0 * tpi;
+        return Tile{img0, (tt / tpr) * 16, (tt % tpr) * 16, n_blk};
+    };
 
     if (producer) {
         // ---- the DMA side.  Patch: lane l of piece p feeds patch pixel q = 8 p + l / 8, physical chunk l % 8 (logical ^ q & 7);
         //      producer w issues pieces w, w + 4, .. (11 or 10).  Weights: a group = 3 slabs = 24 pieces of 8 rows, six per producer;
         //      LDS row R of a slab holds output channel acc_channel(R / 16, R % 16).
+        //      Groups and chunks are numbered through ALL the workgroup's tiles: G = tile * ngroups + g, C = tile * nchunks + ch
+        //      (ngroups is a multiple of 3 and nchunks even: ring third G % 3 and patch buffer C & 1 carry on across tiles).
+        const int Gtot = ntiles * ngroups, Ctot = ntiles * nchunks;
         const uint16_t* const in_ptr = a.in;
         int p_src[11];
+        int p_tile = -1;
+        auto issue_patch = [&](int C) {
+            const int i = C / nchunks, ch = C - i * nchunks;
+            if (i != p_tile) {
+                p_tile = i;
+                const Tile t = tile_of(i);
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            int q = (w + 4 * i) * 8 + drow;
-            q = q < kNPix ? q : kNPix - 1;
-            const int py = q / 18, px = q - py * 18;
-            p_src[i] = img0 * a.in_img + (y0 + py) * a.in_row + (x0 + px) * a.in_pix + ((dchunk ^ (q & 7)) * 8);
-        }
-        auto issue_patch = [&](int ch) {
+                for (int k = 0; k < 11; ++k) {
+                    int q = (w + 4 * k) * 8 + drow;
+                    q = q < kNPix ? q : kNPix - 1;
+                    const int py = q / 18, px = q - py * 18;
+                    p_src[k] = t.img0 * a.in_img + (t.y0 + py) * a.in_row + (t.x0 + px) * a.in_pix + ((dchunk ^ (q & 7)) * 8);
+                }
+            }
             unsigned char* const buf = patch0 + (ch & 1) * kPatch;
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                const int p = w + 4 * i;
-                if (p < kNDma) dma16(in_ptr + p_src[i] + ch * 64, buf + p * 1024);
+            for (int k = 0; k < 11; ++k) {
+                const int p = w + 4 * k;
+                if (p < kNDma) dma16(in_ptr + p_src[k] + ch * 64, buf + p * 1024);
             }
         };
         const uint16_t* w_src[6];
         int w_slot[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int j = w + 4 * i, t = j >> 3, pc = j & 7, row = pc * 8 + drow;
-            w_src[i] = a.w + (size_t)(n_blk + acc_channel(row >> 4, row & 15)) * Ktot + ((dchunk ^ (row & 7)) * 8);
-            w_slot[i] = t * kSlab + pc * 1024;
+        for (int k = 0; k < 6; ++k) {
+            const int j = w + 4 * k;
+            w_slot[k] = (j >> 3) * kSlab + (j & 7) * 1024;
         }
-        auto issue_group = [&](int g) {          // group g = (chunk g / 3, kernel row g % 3): taps 3 r + t, K-step (tap * nchunks + chunk)
+        int w_tile = -1;
+        auto issue_group = [&](int G) {          // group g = (chunk g / 3, kernel row g % 3): taps 3 r + t, K-step (tap * nchunks + chunk)
+            const int i = G / ngroups, g = G - i * ngroups;
+            if (i != w_tile) {
+                w_tile = i;
+                const int n_blk = tile_of(i).n_blk;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int row = ((w + 4 * k) & 7) * 8 + drow;
+                    w_src[k] = a.w + (size_t)(n_blk + acc_channel(row >> 4, row & 15)) * Ktot + ((dchunk ^ (row & 7)) * 8);
+                }
+            }
             const int ch = g / 3, r = g - 3 * ch;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int t = (w + 4 * i) >> 3;
-                dma16(w_src[i] + (size_t)((3 * r + t) * nchunks + ch) * 64, ring + r * 3 * kSlab + w_slot[i]);
+            for (int k = 0; k < 6; ++k) {
+                const int t = (w + 4 * k) >> 3;
+                dma16(w_src[k] + (size_t)((3 * r + t) * nchunks + ch) * 64, ring + r * 3 * kSlab + w_slot[k]);
             }
         };
         issue_patch(0);
@@ -157,19 +182,19 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         wait_vmcnt<12>();                        // tap 2
         __builtin_amdgcn_s_barrier();
-        // barrier B_g (the consumers' barrier behind the reads of group g's last tap): group g + 1 (and, at a chunk's end, the next
-        // chunk's patch) has landed -- what was issued at B_(g-1) may stay in flight (counts below: a wave's MINIMUM, wave 0 issues
-        // 11 patch pieces: a count below the truth only waits for more); then the ring third of group g is refilled with group
-        // g + 3 and, at a chunk's first group, the other patch buffer with the next chunk's patch
-        for (int g = 0; g + 1 < ngroups; ++g) {
-            const bool more = g + 2 < ngroups;
-            const bool with_patch = g >= 1 && (g - 1) % 3 == 0 && (g - 1) / 3 + 1 < nchunks;
+        // barrier B_G (the consumers' barrier behind the reads of group G's last tap): group G + 1 (and, at a chunk's end, the next
+        // chunk's patch) has landed -- what was issued at B_(G-1) may stay in flight (counts below: a wave's MINIMUM, wave 0 issues
+        // 11 patch pieces: a count below the truth only waits for more); then the ring third of group G is refilled with group
+        // G + 3 and, at a chunk's first group, the other patch buffer with the next chunk's patch
+        for (int G = 0; G + 1 < Gtot; ++G) {
+            const bool more = G + 2 < Gtot;
+            const bool with_patch = G >= 1 && (G - 1) % 3 == 0 && (G - 1) / 3 + 1 < Ctot;
             if (!more) wait_vmcnt<0>();
             else if (with_patch) wait_vmcnt<16>();
             else wait_vmcnt<6>();
             __builtin_amdgcn_s_barrier();
-            if (g + 3 < ngroups) issue_group(g + 3);
-            if (g % 3 == 0 && g / 3 + 1 < nchunks) issue_patch(g / 3 + 1);
+            if (G + 3 < Gtot) issue_group(G + 3);
+            if (G % 3 == 0 && G / 3 + 1 < Ctot) issue_patch(G / 3 + 1);
         }
         return;
     }
@@ -189,14 +214,7 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
             const int q = qb + r * 18 + dx;
             xo[r][dx] = smem_base + kRing + q * 128 + ((fq ^ (q & 7)) * 16);
         }
-    f32x4 acc[4][4];                        // start at the folded-BN bias of the tile's rows (channels acc_channel(i, 4 fq + e))
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n_blk + 32 * (i >> 1) + 8 * fq + 4 * (i & 1));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b.x, b.y, b.z, b.w};
-    }
-
+    f32x4 acc[4][4];
     bf16x8 wfr[2][2][4], xfr[2][2][4];
     uint32_t xa[4];                         // ^ 64 of the four pixel addresses of the tap being read next
 #define P4_SB __builtin_amdgcn_sched_barrier(0);
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
         P4_SB                                                                                  \
     }
-    // the 32 MFMAs of the very last tap (set SET)
+    // the 32 MFMAs of a tile's last tap (set SET)
 #define P4_LAST(SET)                                                                           \
     {                                                                                          \
         P4_M2(SET, 0, 0, 0) P4_M2(SET, 0, 0, 2) P4_M2(SET, 0, 1, 0) P4_M2(SET, 0, 1, 2)         \
@@ -238,8 +256,8 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
         P4_M2(SET, 1, 2, 0) P4_M2(SET, 1, 2, 2) P4_M2(SET, 1, 3, 0) P4_M2(SET, 1, 3, 2)         \
     }
     // taps 1..8 of a chunk whose tap 0 sits in set S0 (= chunk parity: nine taps per chunk) and whose patch is at POFF; the group
-    // barriers behind the reads of taps 2, 5 and (unless it is the last chunk's) 8
-#define P4_CHUNK(S0, POFF, LASTCH, FIRSTCH)                                                    \
+    // barriers behind the reads of taps 2, 5 and (unless it is the last chunk of the workgroup's last tile) 8
+#define P4_CHUNK(S0, POFF, VERYLAST, FIRSTCH)                                                  \
     {                                                                                          \
         if (FIRSTCH) P4_BAR                                                                    \
         P4_STEP(1, (S0) ^ 1, POFF)                                                             \
@@ -249,39 +267,71 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
         P4_STEP(3, (S0) ^ 1, POFF) P4_STEP(4, S0, POFF) P4_STEP(5, (S0) ^ 1, POFF)             \
         P4_BAR                                                                                 \
         P4_STEP(6, S0, POFF) P4_STEP(7, (S0) ^ 1, POFF) P4_STEP(8, S0, POFF)                   \
-        if (!(LASTCH)) P4_BAR                                                                  \
+        if (!(VERYLAST)) P4_BAR                                                                \
     }
-    __builtin_amdgcn_s_barrier();                                  // the first patch and tap 0's slab have landed (taps 1 and 2: a barrier each, first chunk only)
-    P4STAMP(1);
-    // tap 0 of chunk 0 -> set 0
-    P4_XA(0, 0) P4_XA(1, 0) P4_XA(2, 0) P4_XA(3, 0)
-    P4_RW(0, 0, 0, 0) P4_RW(0, 0, 1, 0) P4_RW(0, 0, 2, 0) P4_RW(0, 0, 3, 0)
-    P4_RX(0, 0, 0, 0, 0) P4_RX(0, 0, 1, 0, 0) P4_RX(0, 0, 2, 0, 0) P4_RX(0, 0, 3, 0, 0)
-    P4_RW(0, 1, 0, 0) P4_RW(0, 1, 1, 0) P4_RW(0, 1, 2, 0) P4_RW(0, 1, 3, 0)
-    P4_RX(0, 1, 0, 0, 0) P4_RX(0, 1, 1, 0, 0) P4_RX(0, 1, 2, 0, 0) P4_RX(0, 1, 3, 0, 0)
-    P4_XA(0, 1) P4_XA(1, 1) P4_XA(2, 1) P4_XA(3, 1)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    P4_SB
-    for (int ch = 0; ch < nchunks; ch += 2) {          // (nchunks is even: two chunks per round, sets and patch buffers alternate)
-        P4_CHUNK(0, 0, false, ch == 0)
-        P4_STEP(0, 1, kPatch)                          // tap 0 of the odd chunk (patch buffer 1) beside tap 8 of the even one
-        const bool last = ch + 2 >= nchunks;
-        P4_CHUNK(1, kPatch, last, false)
-        if (!last) P4_STEP(0, 0, 0)                    // tap 0 of the next even chunk beside tap 8 of the odd one
-    }
-    P4STAMP(2);
-    // the epilogue's loads go out before the last tap's MFMAs (one fragment set is dead by now: its registers take them)
-    const size_t org = (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + 4 * w) * a.out_row + (size_t)(x0 + frow) * a.out_pix + n_blk + 8 * fq;
-    uint4 resv[8];
-    if (a.res) {
+    for (int it = 0; it < ntiles; ++it) {
+        const Tile tl = tile_of(it);
+        // the accumulators start at the folded-BN bias of the tile's rows (channels acc_channel(i, 4 fq + e))
 #pragma unroll
-        for (int c = 0; c < 8; ++c) resv[c] = *reinterpret_cast<const uint4*>(a.res + org + (size_t)(c >> 1) * a.out_row + 32 * (c & 1));
-    } else {
+        for (int i = 0; i < 4; ++i) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + tl.n_blk + 32 * (i >> 1) + 8 * fq + 4 * (i & 1));
 #pragma unroll
-        for (int c = 0; c < 8; ++c) resv[c] = make_uint4(0u, 0u, 0u, 0u);
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        // first tile: the first patch and tap 0's slab have landed (taps 1 and 2: a barrier each, first chunk only); later tiles:
+        // the barrier behind the previous tile's last reads has published this tile's first patch and group
+        if (it == 0) __builtin_amdgcn_s_barrier();
+        P4STAMP(1);
+        // tap 0 of chunk 0 -> set 0
+        P4_XA(0, 0) P4_XA(1, 0) P4_XA(2, 0) P4_XA(3, 0)
+        P4_RW(0, 0, 0, 0) P4_RW(0, 0, 1, 0) P4_RW(0, 0, 2, 0) P4_RW(0, 0, 3, 0)
+        P4_RX(0, 0, 0, 0, 0) P4_RX(0, 0, 1, 0, 0) P4_RX(0, 0, 2, 0, 0) P4_RX(0, 0, 3, 0, 0)
+        P4_RW(0, 1, 0, 0) P4_RW(0, 1, 1, 0) P4_RW(0, 1, 2, 0) P4_RW(0, 1, 3, 0)
+        P4_RX(0, 1, 0, 0, 0) P4_RX(0, 1, 1, 0, 0) P4_RX(0, 1, 2, 0, 0) P4_RX(0, 1, 3, 0, 0)
+        P4_XA(0, 1) P4_XA(1, 1) P4_XA(2, 1) P4_XA(3, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P4_SB
+        for (int ch = 0; ch < nchunks; ch += 2) {          // (nchunks is even: two chunks per round, sets and patch buffers alternate)
+            P4_CHUNK(0, 0, false, it == 0 && ch == 0)
+            P4_STEP(0, 1, kPatch)                          // tap 0 of the odd chunk (patch buffer 1) beside tap 8 of the even one
+            const bool last = ch + 2 >= nchunks;
+            P4_CHUNK(1, kPatch, last && it + 1 == ntiles, false)
+            if (!last) P4_STEP(0, 0, 0)                    // tap 0 of the next even chunk beside tap 8 of the odd one
+        }
+        P4STAMP(2);
+        // the epilogue's loads go out before the last tap's MFMAs (one fragment set is dead by now: its registers take them)
+        const size_t org = (size_t)a.out_off + (size_t)tl.img0 * a.out_img + (size_t)(tl.y0 + 4 * w) * a.out_row + (size_t)(tl.x0 + frow) * a.out_pix + tl.n_blk + 8 * fq;
+        uint4 resv[8];
+        if (a.res) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) resv[c] = *reinterpret_cast<const uint4*>(a.res + org + (size_t)(c >> 1) * a.out_row + 32 * (c & 1));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) resv[c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        P4_SB
+        P4_LAST(1)                                         // tap 8 of the last (odd) chunk: set (1 + 8) & 1 = 1
+        P4STAMP(3);
+        // ---- epilogue straight from registers (conv_wres.hip): accumulator tiles (2 h, 2 h + 1) of pixel row j hold channels
+        //      n_blk + 32 h + 8 fq .. + 7 of pixel (4 w + j, frow): residual, ReLU, pack, one 16-byte store per piece
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int j = c >> 1, h = c & 1;
+            const size_t off = org + (size_t)j * a.out_row + 32 * h;
+            const f32x4 lo4 = acc[2 * h][j], hi4 = acc[2 * h + 1][j];
+            const uint4 r = resv[c];            // (zeros without a residual: +0.0 in either element type)
+            float v[8] = {lo4[0] + Elem<F16>::lo(r.x), lo4[1] + Elem<F16>::hi(r.x), lo4[2] + Elem<F16>::lo(r.y), lo4[3] + Elem<F16>::hi(r.y),
+                          hi4[0] + Elem<F16>::lo(r.z), hi4[1] + Elem<F16>::hi(r.z), hi4[2] + Elem<F16>::lo(r.w), hi4[3] + Elem<F16>::hi(r.w)};
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<uint4*>(a.out + off) =
+                make_uint4(Elem<F16>::pack2(v[0], v[1]), Elem<F16>::pack2(v[2], v[3]), Elem<F16>::pack2(v[4], v[5]), Elem<F16>::pack2(v[6], v[7]));
+        }
+        P4_SB
+        P4STAMP(4);
     }
-    P4_SB
-    P4_LAST(1)                                         // tap 8 of the last (odd) chunk: set (1 + 8) & 1 = 1
 #undef P4_CHUNK
 #undef P4_LAST
 #undef P4_STEP
@@ -292,26 +342,6 @@ __global__ __launch_bounds__(512) void conv3x3_p4_kernel(const ConvArgs a) {
 #undef P4_WO
 #undef P4_WB
 #undef P4_SB
-
-    P4STAMP(3);
-    // ---- epilogue straight from registers (conv_wres.hip): accumulator tiles (2 h, 2 h + 1) of pixel row j hold channels
-    //      n_blk + 32 h + 8 fq .. + 7 of pixel (4 w + j, frow): residual, ReLU, pack, one 16-byte store per piece
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int j = c >> 1, h = c & 1;
-        const size_t off = org + (size_t)j * a.out_row + 32 * h;
-        const f32x4 lo4 = acc[2 * h][j], hi4 = acc[2 * h + 1][j];
-        const uint4 r = resv[c];            // (zeros without a residual: +0.0 in either element type)
-        float v[8] = {lo4[0] + Elem<F16>::lo(r.x), lo4[1] + Elem<F16>::hi(r.x), lo4[2] + Elem<F16>::lo(r.y), lo4[3] + Elem<F16>::hi(r.y),
-                      hi4[0] + Elem<F16>::lo(r.z), hi4[1] + Elem<F16>::hi(r.z), hi4[2] + Elem<F16>::lo(r.w), hi4[3] + Elem<F16>::hi(r.w)};
-        if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *reinterpret_cast<uint4*>(a.out + off) =
-            make_uint4(Elem<F16>::pack2(v[0], v[1]), Elem<F16>::pack2(v[2], v[3]), Elem<F16>::pack2(v[4], v[5]), Elem<F16>::pack2(v[6], v[7]));
-    }
-    P4STAMP(4);
 #ifdef SPSP_CONV_STAMPS
     if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[8] = p4_bar_;
 #endif
@@ -328,11 +358,14 @@ bool conv_p4_supported(const ConvArgs& a) {
            a.M % 256 == 0 && a.N % 64 == 0 && a.Ho == a.Wo && a.Wo % 16 == 0 && !a.pool_out && a.out && a.in_pix == a.chunks * 64;
 }
 
-int launch_conv_p4(const ConvArgs& a0, hipStream_t stream) {
+int launch_conv_p4(const ConvArgs& a0, int max_workgroups, hipStream_t stream) {
     SPSP_REQUIRE(conv_p4_supported(a0), "conv_p4: needs a 3x3 stride-1 convolution on maps >= 16 wide, whole 256-pixel tiles, an even number of input chunks");
     ConvArgs a = a0;
     a.xcd_n = conv_patch_xcd_n(a, 256, 64);
-    const int grid = (a.M / 256) * (a.N / 64);
+    // fewer workgroups than tiles: persistent, tiles blockIdx.x + i * grid (a multiple of 8: a workgroup's tiles stay on its XCD)
+    const int tiles = (a.M / 256) * (a.N / 64);
+    const int cap = max_workgroups >= 8 ? max_workgroups / 8 * 8 : 8;
+    const int grid = tiles <= cap ? tiles : cap;
     SPSP_TRY((ensure_dynamic_lds<&conv3x3_p4_kernel<true>>(kLds)));
     SPSP_TRY((ensure_dynamic_lds<&conv3x3_p4_kernel<false>>(kLds)));
 #ifdef SPSP_CONV_STAMPS

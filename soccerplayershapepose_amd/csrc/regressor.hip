@@ -318,6 +318,7 @@ struct spsp_regressor {
     // pipeline, same box: 120.8 k -> 127.6 k players/s with layer1 on 1/4 (1/8: 124.3 k, 1/16: 106.9 k), 128.6 k with the stem bands
     // as well (bands of 128 rows = 32 workgroups: 110.9 k) -- tools/ab_pipeline.py, profiles/r04_ab_narrow.txt.  One batch in flight
     // pays for it (layer1 61 -> ~240 us): plan "latency" keeps the chip-filling grids.
+    int p4_cu_div = 1;                  // conv_p4's workgroups: at most num_cus / this (persistent over the tiles beyond)
     int stem_band = 0;                  // conv rows per stem workgroup when coarser than the grid-filling default (32, 64, 128: the whole image)
     int wres_cu_div = 1;                // layer1's persistent workgroups: num_cus / this (2: twice the tiles per workgroup, half the chip)
     bool use_s2rs = true;               // layer2.0 on conv_s2rs.hip (weights stationary in registers); off: conv_s2.hip like the other two
@@ -359,7 +360,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
         if (((r->p4_layers >> L) & 1) && conv_p4_supported(a)) {       // layer2; layer3 in plan "throughput": no K split, producer waves
             ProfScope ps(ctx, kKConvP4, st, true);
-            return launch_conv_p4(a, st);
+            return launch_conv_p4(a, ctx->num_cus / r->p4_cu_div, st);
         }
         ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
         return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], r->patch_nch[L],
@@ -694,6 +695,10 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)
+        case SPSP_DEBUG_PLAN_P4_CUS:
+            SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "spsp_regressor_debug: conv_p4 on 1 / %d of the CUs", value);
+            r->p4_cu_div = value;
+            return SPSP_OK;
         case SPSP_DEBUG_PLAN_WRES_CUS:
             SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8 || value == 16, "spsp_regressor_debug: layer1 on 1 / %d of the CUs", value);
             r->wres_cu_div = value;

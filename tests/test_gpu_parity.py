@@ -346,9 +346,11 @@ def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
 
 def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
     """Plan "throughput" launches the persistent kernels narrow -- layer1 (conv_wres.hip) on a quarter of the CUs, the stem
-    (conv_stem.hip) in bands of up to 64 conv rows -- and plan "latency" chip-filling (`SPSP_DEBUG_PLAN_WRES_CUS`,
-    `SPSP_DEBUG_PLAN_STEM_BAND`).  Which workgroup computes a tile changes, nothing about the tile: the pooled stem map, layer1's
-    map and the regressor outputs are equal bit for bit at B = 32 (64-row bands), 22 (32-row bands) and 3, both element types;
+    (conv_stem.hip) in bands of up to 64 conv rows, layer2 / layer3 (conv_p4.hip) on 64 workgroups that walk 4 / 2 tiles each
+    with the DMA stream running on across the tile boundary -- and plan "latency" chip-filling (`SPSP_DEBUG_PLAN_WRES_CUS`,
+    `SPSP_DEBUG_PLAN_STEM_BAND`, `SPSP_DEBUG_PLAN_P4_CUS`).  Which workgroup computes a tile changes, nothing about the tile: the pooled stem map, layer1's
+    map, layer2's / layer3's maps and the regressor outputs are equal bit for bit at B = 32 (64-row bands), 22 (32-row bands; 176
+    conv_p4 tiles on 64 / 32 workgroups: uneven tile counts) and 3, both element types;
     and the two named plans differ only by layer3's summation order (conv_p4.hip against conv_patch.hip)."""
     from soccerplayershapepose_amd import runtime as rt
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
@@ -360,10 +362,12 @@ def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
             x, _ = S.proxy_crops(B, seed=40 + B)
             native = reg.pack(torch.from_numpy(x).to(dev))
             got = []
-            for div, band in ((1, 0), (4, 64), (2, 32), (16, 128)):
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_P4, 6), 'debug')
+            for div, band, p4div in ((1, 0, 1), (4, 64, 4), (2, 32, 2), (16, 128, 8)):
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_WRES_CUS, div), 'debug')
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM_BAND, band), 'debug')
-                out = [t.clone() for t in reg(native)] + [reg.read_stage(s_, B).clone() for s_ in (1, 2)]
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_P4_CUS, p4div), 'debug')
+                out = [t.clone() for t in reg(native)] + [reg.read_stage(s_, B).clone() for s_ in (1, 2, 3, 4)]
                 torch.cuda.synchronize()
                 reg.check_status()
                 got.append(out)

@@ -29,17 +29,14 @@ def patch(L, tile, ring, db):
 
 
 prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in layers]
-base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), (_abi.DEBUG_PLAN_P4, 6)]
-W, SB = _abi.DEBUG_PLAN_WRES_CUS, _abi.DEBUG_PLAN_STEM_BAND
+base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), (_abi.DEBUG_PLAN_P4, 6), (_abi.DEBUG_PLAN_WRES_CUS, 4), (_abi.DEBUG_PLAN_STEM_BAND, 64)]
+P = _abi.DEBUG_PLAN_P4_CUS
 PLANS = {
-    'conv_p4, layer1 on all CUs, stem bands 16': base + [(W, 1)],
-    'layer1 on 1/4': base + [(W, 4)],
-    'layer1 on 1/8': base + [(W, 8)],
-    'layer1 on 1/16': base + [(W, 16)],
-    'layer1 on 1/4, stem bands 32': base + [(W, 4), (SB, 32)],
-    'layer1 on 1/4, stem bands 64': base + [(W, 4), (SB, 64)],
-    'layer1 on 1/4, stem bands 128': base + [(W, 4), (SB, 128)],
-    'layer1 on 1/8, stem bands 64': base + [(W, 8), (SB, 64)],
+    'plan throughput so far (conv_p4 one tile per workgroup)': base + [(P, 1)],
+    'conv_p4 on at most 1/2 of the CUs': base + [(P, 2)],
+    'conv_p4 on at most 1/4': base + [(P, 4)],
+    'conv_p4 on at most 1/8': base + [(P, 8)],
+    'layer2 only on conv_p4, 1/4': base + [(_abi.DEBUG_PLAN_P4, 2), (P, 4)],
 }
 if os.environ.get('AB_OLD_PLANS'):
     PLANS = {
