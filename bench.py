@@ -395,13 +395,15 @@ def main():
         nk = r.lib.spsp_profile_num_kernels()
         ms = (C.c_double * nk)()
         cnt = (C.c_int * nk)()
-        r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'spsp_profile_read')
+        wgs = (C.c_double * nk)()
+        r.check(r.lib.spsp_profile_read_grids(r.ctx, nk, ms, cnt, wgs), 'spsp_profile_read_grids')
         out = {}
         for i in range(nk):
             if cnt[i]:
                 out[r.lib.spsp_profile_kernel_name(i).decode()] = {'id': i, 'launches_per_step': cnt[i] / nsteps,
                                                                    'avg_us': 1e3 * ms[i] / cnt[i],
-                                                                   'us_per_step': 1e3 * ms[i] / nsteps}
+                                                                   'us_per_step': 1e3 * ms[i] / nsteps,
+                                                                   'avg_workgroups': wgs[i] / cnt[i]}
         return out
 
     # ---- untimed per-kernel pass: every kernel bracketed by a HIP-event pair on its launch stream, ONE batch in
@@ -438,6 +440,9 @@ def main():
         if fl > 0:
             cands[k] = fl * B
     dom = max(cands, key=lambda k: kernels_iso[k]['us_per_step'])
+    cands_tp = {k: r.lib.spsp_profile_kernel_flop_per_crop(v['id']) * B for k, v in kernels_iso_tp.items()
+                if r.lib.spsp_profile_kernel_flop_per_crop(v['id']) > 0 and v['avg_workgroups'] > 0}
+    num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides.  Only the dominant kernel keeps
     # its event pair here: a pair is a barrier on its in-order stream, and bracketing all ~60 launches of a step costs
@@ -661,6 +666,13 @@ def main():
             'kernels_isolated_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_avg_us': {k: round(v['avg_us'], 2) for k, v in kernels_iso.items()},
             'kernels_isolated_throughput_plan_us_per_step': {k: round(v['us_per_step'], 2) for k, v in kernels_iso_tp.items()},
+            # the MFMA kernels of plan "throughput" against the peak of the CUs their launches occupy (one workgroup per CU: 150 KB of
+            # LDS each; a launch of 64 workgroups cannot use more than a quarter of the chip and is not meant to)
+            'mfma_kernels_throughput_plan': {k: {'launches_per_step': kernels_iso_tp[k]['launches_per_step'], 'avg_us': round(kernels_iso_tp[k]['avg_us'], 2),
+                                                 'avg_workgroups': round(kernels_iso_tp[k]['avg_workgroups'], 1),
+                                                 'frac_of_chip': round(f / (kernels_iso_tp[k]['avg_us'] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                                 'frac_of_cus_used': round(f / (kernels_iso_tp[k]['avg_us'] * 1e-6) / 1e12 / (MFMA_PEAK_TFLOPS * min(1.0, kernels_iso_tp[k]['avg_workgroups'] / num_cus)), 4)}
+                                             for k, f in cands_tp.items()},
         }
         # cross-check against the TRACKED rocprofv3 kernel trace of the isolated command (same build): the live figure must be
         # reproducible from a file under profiles/

@@ -74,6 +74,9 @@ const char* spsp_profile_kernel_name(int id);
 double      spsp_profile_kernel_flop_per_crop(int id);
 int         spsp_profile_kernel_in_default_plan(int id);
 int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);
+/* the same, and per kernel the workgroups of its single-launch scopes summed (0 for the others): launches narrower than the chip
+ * (plan "throughput") are priced against the CUs they occupy */
+int         spsp_profile_read_grids(spsp_ctx* ctx, int n, double* total_ms, int* launches, double* total_workgroups);
 /* Instead of the sums: one (kernel id, stream, start, stop) record per bracketed launch site, times in ms relative to the
  * first record; clears the records.  For timeline studies of the multi-stream pipeline (tools/timeline.py). */
 int         spsp_profile_timeline(spsp_ctx* ctx, int max_records, int* ids, unsigned long long* streams, double* start_ms,

@@ -128,6 +128,7 @@ _PROTOS = {
     'spsp_profile_timeline': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'spsp_profile_read': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    'spsp_profile_read_grids': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     'spsp_conv_name': (C.c_char_p, [C.c_int]),
     'spsp_conv_bn_name': (C.c_char_p, [C.c_int]),
     'spsp_regressor_load': (C.c_int, [_vp, C.POINTER(RegressorWeights), C.c_int, C.c_int, C.POINTER(_vp)]),

@@ -105,7 +105,7 @@ enum KernelId {
     kKConvP4,          // conv3x3_p4_kernel (3x3 / 1 of layer2 and, plan "throughput", layer3: 256-pixel tiles, no K split, producer waves)
     kKNumKernels
 };
-struct ProfRec { int id; hipEvent_t start, stop; hipStream_t stream; };
+struct ProfRec { int id; hipEvent_t start, stop; hipStream_t stream; unsigned workgroups; };
 }  // namespace spsp
 
 struct spsp_ctx {
@@ -119,7 +119,7 @@ struct spsp_ctx {
 
 namespace spsp {
 // Profiling events of the scope the current thread is inside (nullptr: none / profiling off).
-struct ProfLaunch { hipEvent_t start, stop; bool single, used; };
+struct ProfLaunch { hipEvent_t start, stop; bool single, used; unsigned workgroups; };
 inline thread_local ProfLaunch* tl_prof = nullptr;
 
 // Times the launches issued during its lifetime when profiling is enabled.
@@ -129,8 +129,10 @@ inline thread_local ProfLaunch* tl_prof = nullptr;
 //                   a quarter of a 10 us convolution);
 //   single = false: legacy bracket, an event recorded before and after whatever the scope launches.
 struct ProfScope {
-    ProfLaunch pl{nullptr, nullptr, false, false};
+    ProfLaunch pl{nullptr, nullptr, false, false, 0u};
     hipStream_t st;
+    spsp_ctx* ctx_ = nullptr;
+    size_t rec_ = 0;
     bool active = false;
     ProfScope(spsp_ctx* c, int id, hipStream_t s, bool single = false) : st(s) {
         if (!c || !c->prof_on || (c->prof_only >= 0 && c->prof_only != id)) return;
@@ -139,14 +141,16 @@ struct ProfScope {
             if (!c->prof_free.empty()) { e = c->prof_free.back(); c->prof_free.pop_back(); }
             else if (hipEventCreate(&e) != hipSuccess) return;
         }
-        pl = {ev[0], ev[1], single, false};
+        pl = {ev[0], ev[1], single, false, 0u};
         active = true;
         if (single) tl_prof = &pl;
         else (void)hipEventRecord(ev[0], st);
-        c->prof_recs.push_back({id, ev[0], ev[1], st});
+        ctx_ = c; rec_ = c->prof_recs.size();
+        c->prof_recs.push_back({id, ev[0], ev[1], st, 0u});
     }
     ~ProfScope() {
         if (!active) return;
+        if (rec_ < ctx_->prof_recs.size()) ctx_->prof_recs[rec_].workgroups = pl.workgroups;
         if (pl.single) {
             tl_prof = nullptr;
             if (!pl.used) { (void)hipEventRecord(pl.start, st); (void)hipEventRecord(pl.stop, st); }   // nothing was launched
@@ -162,6 +166,7 @@ inline void launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
     ProfLaunch* const p = tl_prof;
     if (p && p->single && !p->used) {
         p->used = true;
+        p->workgroups = grid.x * grid.y * grid.z;
         hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, p->start, p->stop, 0, static_cast<KArgs>(args)...);
     } else {
         hipLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, static_cast<KArgs>(args)...);

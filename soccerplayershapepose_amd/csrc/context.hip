@@ -90,15 +90,18 @@ int spsp_profile_timeline(spsp_ctx* ctx, int max_records, int* ids, unsigned lon
     return SPSP_OK;
 }
 
-int spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches) {
+int spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches) { return spsp_profile_read_grids(ctx, n, total_ms, launches, nullptr); }
+
+int spsp_profile_read_grids(spsp_ctx* ctx, int n, double* total_ms, int* launches, double* total_workgroups) {
     SPSP_REQUIRE(ctx && total_ms && launches && n >= spsp::kKNumKernels, "spsp_profile_read: need %d slots", spsp::kKNumKernels);
-    for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; }
+    for (int i = 0; i < n; ++i) { total_ms[i] = 0.0; launches[i] = 0; if (total_workgroups) total_workgroups[i] = 0.0; }
     for (auto& r : ctx->prof_recs) {
         SPSP_HIP_CHECK(hipEventSynchronize(r.stop));
         float ms = 0.f;
         SPSP_HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
         total_ms[r.id] += ms;
         launches[r.id] += 1;
+        if (total_workgroups) total_workgroups[r.id] += r.workgroups;
         ctx->prof_free.push_back(r.start);
         ctx->prof_free.push_back(r.stop);
     }
