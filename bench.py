@@ -65,6 +65,7 @@ def parse(argv=None):
                     help='each step also builds the native proxy input on the GPU from silhouettes [B,512,512] u8 + joints2D (SURVEY 8f-1)')
     ap.add_argument('--rehearse-dist', action='store_true',
                     help='run the N>1 code path (RCCL communicators, per-step all-gather, barriers) even with one rank')
+    ap.add_argument('--plan-hooks', default='', help=argparse.SUPPRESS)         # experiment: 'what=value,...' (SPSP_DEBUG_PLAN_*) on every slot's regressor
     ap.add_argument('--probe', action='store_true', help=argparse.SUPPRESS)       # diagnostic: re-time the pipeline after the timed region (stderr)
     ap.add_argument('--inputs', type=int, default=0,
                     help='distinct resident input batches rotated through the steps (0 = one per pipeline slot, at least 4): every step '
@@ -311,7 +312,12 @@ def main():
     def make_pipe(precision, streams=None):
         mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=precision).load_state_dict(sd)
         mk_s = lambda: SMPL(model, max_batch=B)
-        return PlayerPipeline(mk_r, mk_s, dev, depth=max(1, args.depth), streams=streams)
+        p_ = PlayerPipeline(mk_r, mk_s, dev, depth=max(1, args.depth), streams=streams)
+        for kv in filter(None, args.plan_hooks.split(',')):
+            what, val = (int(v) for v in kv.split('='))
+            for sl in p_.slots:
+                rt.get(dev).check(rt.get(dev).lib.spsp_regressor_debug(sl.regressor.handle, what, val), 'spsp_regressor_debug')
+        return p_
 
     pipe = make_pipe(args.precision)
     reg, smpl = pipe.slots[0].regressor, pipe.slots[0].smpl

@@ -30,14 +30,14 @@ def patch(L, tile, ring, db):
 
 prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in layers]
 base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), (_abi.DEBUG_PLAN_P4, 6), (_abi.DEBUG_PLAN_WRES_CUS, 4), (_abi.DEBUG_PLAN_STEM_BAND, 64)]
-P = _abi.DEBUG_PLAN_P4_CUS
 PLANS = {
-    'plan throughput so far (conv_p4 one tile per workgroup)': base + [(P, 1)],
-    'conv_p4 on at most 1/2 of the CUs': base + [(P, 2)],
-    'conv_p4 on at most 1/4': base + [(P, 4)],
-    'conv_p4 on at most 1/8': base + [(P, 8)],
-    'layer2 only on conv_p4, 1/4': base + [(_abi.DEBUG_PLAN_P4, 2), (P, 4)],
+    'plan throughput': base,
+    'layer4 in 256-pixel tiles (64 workgroups), ring 3, one patch buffer': base + [patch(3, 256, 3, 0)],
+    'layer4 in 256-pixel tiles, ring 2, two patch buffers': base + [patch(3, 256, 2, 1)],
+    'layer3 on conv_patch in 256-pixel tiles (128 workgroups, K split)': base + [(_abi.DEBUG_PLAN_P4, 2), patch(2, 256, 3, 1)],
+    'layer1 on 48 workgroups... (1/4 is 64)': base,
 }
+PLANS.popitem()
 if os.environ.get('AB_OLD_PLANS'):
     PLANS = {
         's2 + layer4 64ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel traces whose summaries are tracked under profiles/ (run on the GPU box through gpurun):
 #   (a) one batch in flight:  tools/regressor_only.py 32 4 f16   -> <tag>_kernel_stats_regressor_only.csv
+#   (c) (a) in plan "throughput" (narrow persistent grids)      -> <tag>_kernel_stats_regressor_only_throughput_plan.csv
 #   (b) four batches in flight, eager: bench.py --no-graphs ...  -> <tag>_kernel_stats_bench_eager.csv
 # usage: tools/gpu_profile.sh <tag>      (writes under gpurun_out/)
 set -o pipefail
@@ -12,6 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$out/${tag}_kt_a" -- python3 "$root/tools/regressor_only.py" 32 4 f16 > "$out/${tag}_kt_a.log" 2>&1 || exit 1
 db=$(find "$out/${tag}_kt_a" -name '*.db' | head -1)
 python3 "$root/profiles/export_rocpd.py" stats "$db" "$out/${tag}_kernel_stats_regressor_only.csv" || exit 1
+rocprofv3 --kernel-trace --stats -d "$out/${tag}_kt_c" -- python3 "$root/tools/regressor_only.py" 32 4 f16 throughput > "$out/${tag}_kt_c.log" 2>&1 || exit 1
+db=$(find "$out/${tag}_kt_c" -name '*.db' | head -1)
+python3 "$root/profiles/export_rocpd.py" stats "$db" "$out/${tag}_kernel_stats_regressor_only_throughput_plan.csv" || exit 1
+rm -rf "$out/${tag}_kt_c"
 rocprofv3 --kernel-trace --stats -d "$out/${tag}_kt_b" -- python3 "$root/bench.py" --no-graphs --no-alt-precision --no-cpu-baseline --steps 60 > "$out/${tag}_kt_b.json" 2> "$out/${tag}_kt_b.log" || exit 1
 db=$(find "$out/${tag}_kt_b" -name '*.db' | head -1)
 python3 "$root/profiles/export_rocpd.py" stats "$db" "$out/${tag}_kernel_stats_bench_eager.csv" || exit 1
