@@ -13,6 +13,10 @@
 // releases the group's ring third (the producers refill it at once with the group three ahead) and publishes the next group,
 // whose first reads go out beside the pending MFMAs.
 //
+// Round 4, measured (profiles/r04_p4_stamps.txt, r04_ab_p4.txt): K loop 15.5 k -> 11.2 k cycles per tile, layer2's launch 13.1 -> 11.7 us;
+// layer3 as one image per workgroup (128 workgroups at B = 32) is slower alone (12.0 -> 14.9 us) and 40 % less CU time: plan
+// "throughput" only.  Launched with fewer workgroups than tiles the kernel is persistent (tile loop below).
+//
 // LDS: ring of 9 weight slabs (three groups of three taps; the slab of tap t of ANY chunk sits in slot t) 72 KB + two 18 x 18
 // patches (one per chunk parity) 82 KB.  Patch image, swizzles, permuted weight rows: conv_patch.hip / conv_wres.hip.
 #include <cstdio>

@@ -29,15 +29,15 @@ def patch(L, tile, ring, db):
 
 
 prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in layers]
-base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64), (_abi.DEBUG_PLAN_P4, 6), (_abi.DEBUG_PLAN_WRES_CUS, 4), (_abi.DEBUG_PLAN_STEM_BAND, 64)]
-PLANS = {
-    'plan throughput': base,
-    'layer4 in 256-pixel tiles (64 workgroups), ring 3, one patch buffer': base + [patch(3, 256, 3, 0)],
-    'layer4 in 256-pixel tiles, ring 2, two patch buffers': base + [patch(3, 256, 2, 1)],
-    'layer3 on conv_patch in 256-pixel tiles (128 workgroups, K split)': base + [(_abi.DEBUG_PLAN_P4, 2), patch(2, 256, 3, 1)],
-    'layer1 on 48 workgroups... (1/4 is 64)': base,
+W, SB, P4, P4C = _abi.DEBUG_PLAN_WRES_CUS, _abi.DEBUG_PLAN_STEM_BAND, _abi.DEBUG_PLAN_P4, _abi.DEBUG_PLAN_P4_CUS
+base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)]
+PLANS = {      # (PlayerPipeline puts its slots in plan "throughput": the hooks below override single choices of it)
+    'chip-filling grids, layer2 / layer3 on conv_patch (round 3)': base + [(P4, 0), (W, 1), (SB, 0)],
+    'chip-filling grids, layer2 + layer3 on conv_p4': base + [(P4, 6), (W, 1), (SB, 0)],
+    'plan "throughput": conv_p4, layer1 on 1/4 of the CUs, stem bands of 64 rows': base + [(P4, 6), (W, 4), (SB, 64)],
+    'the same with layer1 on 1/2, stem bands of 32': base + [(P4, 6), (W, 2), (SB, 32)],
+    'the same with conv_p4 persistent on 1/2 of the CUs': base + [(P4, 6), (W, 4), (SB, 64), (P4C, 2)],
 }
-PLANS.popitem()
 if os.environ.get('AB_OLD_PLANS'):
     PLANS = {
         's2 + layer4 64ch': [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)],
