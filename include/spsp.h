@@ -207,6 +207,7 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_PLAN_LAYER4_CHANNELS 3
 #define SPSP_DEBUG_PLAN_PATCH 4
 #define SPSP_DEBUG_PLAN_PATCH_PRODUCER 5   /* value = layer (1..3) * 10 + (0 | 1): four DMA-only producer waves in that stage's patch kernel */
+#define SPSP_DEBUG_PLAN_S2RS_CUS 11        /* conv_s2rs: tiles per workgroup as for a chip of 1 / value of the CUs (1, 2, 4, 8: 2, 4, 8 tiles at B = 32) */
 #define SPSP_DEBUG_PLAN_P4_CUS 10          /* conv_p4's workgroups: at most 1 / value of the CUs (1, 2, 4, 8), persistent over the tiles beyond */
 #define SPSP_DEBUG_PLAN_STEM_BAND 9        /* conv rows per workgroup of the stem kernel (0: grid-filling default, 32, 64, 128 = one workgroup per crop) */
 #define SPSP_DEBUG_PLAN_WRES_CUS 8         /* layer1's persistent workgroups on 1 / value of the CUs (1, 2, 4, 8, 16): more tiles per resident weight set */

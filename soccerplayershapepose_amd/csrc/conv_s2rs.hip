@@ -14,7 +14,8 @@
 //   * everything else is conv_s2.hip's: the four parity planes (every tap reads 16 consecutive plane pixels: conflict-free),
 //     the K order by plane, waves = 2 pixel groups x 2 K-halves with the accumulator exchange at the end of a tile (through the
 //     first tile's dead plane buffer), permuted weight rows so that a lane stores 8 consecutive channels.
-// Workgroup = 2 tiles (1 for small batches) of 128 output pixels x one 64-channel block; grid = tiles (x 2 blocks / 2 tiles).
+// Workgroup = 2 tiles (1 for small batches; 4 or 8 in plan "throughput": tile t + 2 is requested into the buffer tile t has left, the
+// K-half exchange goes through the finished tile's own buffer) of 128 output pixels x one 64-channel block.
 #include <type_traits>
 
 #include "conv.hpp"
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
         int img0, y0, x0;
         tile_origin(t, img0, y0, x0);
         const uint16_t* const base = in_ptr + (size_t)img0 * a.in_img + (size_t)(2 * y0) * a.in_row + (size_t)(2 * x0) * a.in_pix;
-        unsigned char* const buf = smem + t * kPatch;
+        unsigned char* const buf = smem + (t & 1) * kPatch;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
         // ---- this tile's planes: everything this wave has issued for it has landed, then everybody's
         if (t + 1 < ntiles) wait_vmcnt<kPieces>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        const uint32_t bufo = (uint32_t)(t * kPatch);
+        const uint32_t bufo = (uint32_t)((t & 1) * kPatch);
 
         f32x4 acc[4][4], acc2[4][4];
 #pragma unroll
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
 #undef RS_RX
 #undef RS_SB
 
-        // ---- epilogue: K-half exchange of both accumulator sets through the FIRST tile's plane buffer (dead: the second tile
-        // sits in the other one), then bias (+ ReLU) -> 16-bit, 16-byte stores straight from registers: wave (kw, pg) ends with
+        // ---- epilogue: K-half exchange of both accumulator sets through this tile's own plane buffer (dead; the next tile
+        // sits in the other one; with more than two tiles: through the buffer of the tile itself), then bias (+ ReLU) -> 16-bit, 16-byte stores straight from registers: wave (kw, pg) ends with
         // channel tiles 2 kw, 2 kw + 1 = channels n_blk + 32 kw + 8 fq .. + 7 of its 64 pixels.
         int img0, y0, x0;
         tile_origin(t, img0, y0, x0);
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
         for (int j = 0; j < 4; ++j)
             poff[j] = (size_t)a.out_off + (size_t)img0 * a.out_img + (size_t)(y0 + 4 * pg + j) * a.out_row + (size_t)(x0 + frow) * a.out_pix + cbase;
         {
-            __builtin_amdgcn_s_barrier();                          // every wave is done with the planes of tile 0 (and with the last exchange)
-            float* xch = reinterpret_cast<float*>(smem);           // [set 2][wave 4][8 tiles][64 lanes] f32x4 = 64 KB
+            __builtin_amdgcn_s_barrier();                          // every wave is done with this tile's planes
+            float* xch = reinterpret_cast<float*>(smem + (t & 1) * kPatch);      // [set 2][wave 4][8 tiles][64 lanes] f32x4 = 64 KB
             using I0 = std::integral_constant<int, 0>;
             using I2 = std::integral_constant<int, 2>;
             auto put = [&](auto GIVE) {
@@ -304,6 +305,13 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
             using S1 = std::integral_constant<int, 1>;
             if (kw == 0) { finish(I0{}, S0{}); finish(I0{}, S1{}); } else { finish(I2{}, S0{}); finish(I2{}, S1{}); }
         }
+        // more than two tiles per workgroup (plan "throughput": the 80 KB of weights are fetched once per workgroup): the tile after
+        // next goes into the buffer this tile has just left -- once every wave has read its partner's halves out of it
+        if (t + 2 < ntiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_tile(t + 2);
+        }
     }
 }
 
@@ -320,8 +328,10 @@ int launch_conv_s2rs(const ConvArgs& a, int num_cus, hipStream_t stream) {
     SPSP_REQUIRE(conv_s2rs_supported(a), "conv_s2rs: needs layer2.0's shape (64 -> 128 channels, 32 x 32 output maps, whole pairs of 128-pixel tiles)");
     const int mt = a.M / 128, units = mt * (a.N / 64);
     RsTileMap tm;
-    // two tiles per workgroup once one tile each would need a second round of workgroups
+    // two tiles per workgroup once one tile each would need a second round of workgroups; `num_cus` below the chip's (plan
+    // "throughput": a quarter of it) -> 4 or 8 tiles per resident weight set, as long as they divide the tiles of a block
     tm.tiles_per_wg = units > num_cus ? 2 : 1;
+    while (tm.tiles_per_wg < 8 && units > tm.tiles_per_wg * num_cus && mt % (2 * tm.tiles_per_wg) == 0) tm.tiles_per_wg *= 2;
     const int grid = units / tm.tiles_per_wg;
     tm.paired = grid % 16 == 0 ? 1 : 0;
     SPSP_TRY((ensure_dynamic_lds<&conv3x3s2_kernel<true>>(kLds)));

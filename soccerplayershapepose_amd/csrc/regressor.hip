@@ -317,7 +317,9 @@ struct spsp_regressor {
     // quarter of the CUs (8 tiles per resident weight set), the stem in bands of 64 conv rows (64 workgroups at B = 32).  Four-slot
     // pipeline, same box: 120.8 k -> 127.6 k players/s with layer1 on 1/4 (1/8: 124.3 k, 1/16: 106.9 k), 128.6 k with the stem bands
     // as well (bands of 128 rows = 32 workgroups: 110.9 k) -- tools/ab_pipeline.py, profiles/r04_ab_narrow.txt.  One batch in flight
-    // pays for it (layer1 61 -> ~240 us): plan "latency" keeps the chip-filling grids.
+    // pays for it (layer1 61 -> ~240 us): plan "latency" keeps the chip-filling grids.  Round 4, later: layer2.0 (conv_s2rs: 80 KB of
+    // weights in registers per workgroup) with four tiles per workgroup instead of two: +1.6 % (eight: the same).
+    int s2rs_cu_div = 1;                // conv_s2rs: tiles per resident weight set as if the chip had num_cus / this CUs (2 -> 4 -> 8 tiles)
     int p4_cu_div = 1;                  // conv_p4's workgroups: at most num_cus / this (persistent over the tiles beyond)
     int stem_band = 0;                  // conv rows per stem workgroup when coarser than the grid-filling default (32, 64, 128: the whole image)
     int wres_cu_div = 1;                // layer1's persistent workgroups: num_cus / this (2: twice the tiles per workgroup, half the chip)
@@ -370,7 +372,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
     if (r->use_s2 && r->use_s2rs && conv_s2rs_supported(a)) {   // layer2.0: the same planes, weights stationary in registers
         ProfScope ps(ctx, kKConvS2, st, true);
-        return launch_conv_s2rs(a, ctx->num_cus, st);
+        return launch_conv_s2rs(a, ctx->num_cus / r->s2rs_cu_div, st);
     }
     if (r->use_s2 && conv_s2_supported(a)) {           // 3x3 / 2 + its 1x1 / 2 downsample in whole 128-pixel tiles: parity-plane patch kernel
         ProfScope ps(ctx, kKConvS2, st, true);
@@ -685,6 +687,7 @@ int spsp_regressor_set_plan(spsp_regressor* r, int plan) {
     r->p4_layers = plan == SPSP_PLAN_LATENCY ? 2 : 6;
     r->wres_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 4;
     r->stem_band = plan == SPSP_PLAN_LATENCY ? 0 : 64;
+    r->s2rs_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 2;      // layer2.0: four tiles per resident weight set (128 workgroups at B = 32)
     return SPSP_OK;
 }
 
@@ -695,6 +698,10 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)
+        case SPSP_DEBUG_PLAN_S2RS_CUS:
+            SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "spsp_regressor_debug: conv_s2rs on 1 / %d of the CUs", value);
+            r->s2rs_cu_div = value;
+            return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4_CUS:
             SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "spsp_regressor_debug: conv_p4 on 1 / %d of the CUs", value);
             r->p4_cu_div = value;

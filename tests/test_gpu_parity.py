@@ -288,7 +288,8 @@ def test_layer2_stride2_pair_with_register_stationary_weights_is_bit_identical(d
     and two 128-pixel tiles per workgroup (`SPSP_DEBUG_PLAN_S2RS`; 0 = conv_s2.hip, the streaming kernel of layer3.0 / layer4.0).
     Same products accumulated in the same order, so the regressor outputs and layer2's feature map must equal the streaming
     kernel's bit for bit: B = 32 and 22 (two tiles per workgroup, full and partial grid), 16 and 8 (one tile per workgroup), 3
-    (a grid that is no multiple of 16: the unpaired tile map), both precisions."""
+    (a grid that is no multiple of 16: the unpaired tile map), both precisions; and with four / eight tiles per workgroup (plan
+    "throughput", `SPSP_DEBUG_PLAN_S2RS_CUS`: the tile after next is requested into the buffer a finished tile leaves)."""
     from soccerplayershapepose_amd import runtime as rt
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
     sd = S.regressor_state_dict(seed=0)
@@ -299,15 +300,17 @@ def test_layer2_stride2_pair_with_register_stationary_weights_is_bit_identical(d
             x, _ = S.proxy_crops(B, seed=60 + B)
             native = reg.pack(torch.from_numpy(x).to(dev))
             got = []
-            for rs in (0, 1):
+            for rs, cus in ((0, 1), (1, 1), (1, 2), (1, 4)):      # (cus: 4 and 8 tiles per workgroup where they divide -- plan "throughput")
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2RS, rs), 'debug')
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2RS_CUS, cus), 'debug')
                 out = [t.clone() for t in reg(native)]
                 out.append(reg.read_stage(3, B).clone())
                 torch.cuda.synchronize()
                 reg.check_status()
                 got.append(out)
-            for a, b in zip(*got):
-                assert torch.isfinite(a).all() and torch.equal(a, b)
+            for other in got[1:]:
+                for a, b in zip(got[0], other):
+                    assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
