@@ -360,7 +360,16 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
     a.zero = zero_words; a.nzero = zero_words ? nzero : 0;
     // bands of 16 conv rows (8 per image) fill 256 CUs at 32 crops with one halo step in nine; smaller batches take
     // finer bands so that the grid still covers the chip
-    a.rows_per_band = B * 8 >= num_cus ? 16 : (B * 16 >= num_cus ? 8 : 4);
+    // (cost of a band height = rounds of workgroups x a workgroup's life, prologue 13 k + 12 k cycles per step of two conv rows --
+    // the stamps below: 22 crops are 176 workgroups of 16 rows in ONE round, not 352 of 8 rows in two)
+    {
+        long best = 0;
+        for (int rb = 16; rb >= 4; rb /= 2) {
+            const long wgs = (long)B * (128 / rb), rounds = (wgs + num_cus - 1) / num_cus;
+            const long cost = rounds * (13 + 12 * (rb / 2 + 1));
+            if (best == 0 || cost < best) { best = cost; a.rows_per_band = rb; }
+        }
+    }
     // (plan "throughput": coarser bands = fewer, longer-lived workgroups -- the 114 KB of weights and the halo step are paid per band)
     // -- as long as a quarter of the chip still has a workgroup each
     while (a.rows_per_band < rows_per_band && B * (128 / (2 * a.rows_per_band)) * 4 >= num_cus) a.rows_per_band *= 2;
