@@ -632,7 +632,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 namespace spsp {
 
 bool conv_patch_supported(const ConvArgs& a) {
-    return a.stride == 1 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && a.in_off == 0 && a.M % 256 == 0 && a.N % 64 == 0 &&
+    return a.stride == 1 && a.kw_steps == 3 && a.nsteps == 9 * a.chunks && a.in_off == 0 && a.M % 128 == 0 && a.N % 64 == 0 &&
            a.Ho == a.Wo && (a.Wo == 8 || a.Wo % 16 == 0) && a.splitk <= 1;
 }
 
@@ -654,9 +654,10 @@ int conv_patch_xcd_n(const ConvArgs& a, int tile_pixels, int block_channels) {
 }
 
 int launch_conv_patch(const ConvArgs& a0, bool two_patch_buffers, int tile_pixels, int ring_groups, int block_channels, bool producer_waves, hipStream_t stream) {
-    SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%256==0, N%%64==0)");
+    SPSP_REQUIRE(conv_patch_supported(a0), "conv_patch: unsupported convolution (need 3x3 stride-1 pad-1, M%%128==0, N%%64==0)");
     SPSP_REQUIRE(!a0.pool_out || a0.Wo == 8, "conv_patch: fused avg-pool only for 8x8 maps");
     SPSP_REQUIRE(tile_pixels == 256 || tile_pixels == 128, "conv_patch: tile of %d pixels", tile_pixels);
+    SPSP_REQUIRE(a0.M % tile_pixels == 0, "conv_patch: %d pixels are no whole number of %d-pixel tiles", a0.M, tile_pixels);
     SPSP_REQUIRE(ring_groups == 2 || ring_groups == 3, "conv_patch: weight ring of %d groups", ring_groups);
     SPSP_REQUIRE(block_channels == 64 || (block_channels == 32 && a0.Wo == 8 && tile_pixels == 128 && ring_groups == 3 && a0.N % 32 == 0),
                  "conv_patch: %d-channel blocks (64; 32 for 8 x 8 maps in 128-pixel tiles with a three-group ring)", block_channels);

@@ -359,14 +359,16 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
         ProfScope ps(ctx, kKConvWres, st, true);
         return launch_conv_wres(a, ctx->num_cus / r->wres_cu_div, st);
     }
-    if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 256 pixels
+    if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 128 pixels
         if (((r->p4_layers >> L) & 1) && conv_p4_supported(a)) {       // layer2; layer3 in plan "throughput": no K split, producer waves
             ProfScope ps(ctx, kKConvP4, st, true);
             return launch_conv_p4(a, ctx->num_cus / r->p4_cu_div, st);
         }
         ProfScope ps(ctx, a.Wo == 8 ? kKPatchW8 : kKPatchW16, st, true);
-        return launch_conv_patch(a, r->patch_db[L], r->patch_tile[L], r->patch_ring[L], r->patch_nch[L],
-                                 r->patch_prod[L] && r->patch_tile[L] == 128 && r->patch_ring[L] == 3 && r->patch_db[L], st);
+        // (8 x 8 maps: a batch of 2 mod 4 crops -- the 22-player frame -- is whole 128-pixel tiles, two images each, but no whole 256-pixel ones)
+        const int tile = a.M % 256 == 0 ? r->patch_tile[L] : 128;
+        return launch_conv_patch(a, r->patch_db[L], tile, r->patch_ring[L], r->patch_nch[L],
+                                 r->patch_prod[L] && tile == 128 && r->patch_ring[L] == 3 && r->patch_db[L], st);
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
