@@ -472,9 +472,10 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     const size_t B = max_batch;
     TRY(r->pool.alloc(&r->x0, B * kNativeElems, true));
     TRY(r->pool.alloc(&r->p1, B * 66 * 66 * 64, true));
+    // (layer3's and layer4's maps and the feature rows hold one crop more: an odd batch runs layer4 on B + 1 crops -- below)
     for (int L = 0; L < 4; ++L)
         for (int j = 0; j < 3; ++j)
-            TRY(r->pool.alloc(&r->l[L][j], B * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
+            TRY(r->pool.alloc(&r->l[L][j], (B + (L >= 2 ? 1 : 0)) * (kLayerS[L] + 2) * (kLayerS[L] + 2) * kLayerC[L], true));
     TRY(r->pool.alloc(&r->counters, kCounterWords, true));
     {   // status word the kernels can raise and the host can read without a synchronisation
         void* hp = nullptr;
@@ -539,7 +540,7 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         }
 #endif
     }
-    TRY(r->pool.alloc(&r->feats, B * kFeat));
+    TRY(r->pool.alloc(&r->feats, (B + 1) * kFeat));
     TRY(r->pool.alloc(&r->h1, (B + 31) / 32 * 32 * kHid));      // blocked hand-off layout: whole blocks of 32 players
     TRY(r->pool.alloc(&r->h2, (B + 31) / 32 * 32 * kHid));
 #undef TRY
@@ -605,13 +606,18 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
             ci += 2;
             x = bc;
         } else {
+            // layer4's tiles are PAIRS of 8 x 8 images (conv_s2 / conv_patch): an odd batch would fall back to the implicit-GEMM
+            // ring kernel for all four launches (99 instead of 52 us at 21 crops).  It runs on B + 1 crops instead: the extra crop
+            // is whatever the buffers hold behind the batch (zero-filled at load, finite ever after), every crop's results depend
+            // on that crop alone, and its map / feature row -- room for them is allocated -- are never read.
+            const int Bl = (L == 3 && (B & 1)) ? B + 1 : B;
             // t = relu(bn1(conv1(x))) (3x3 stride 2) and identity = downsample(x) (1x1 stride 2, same input pixels) in ONE launch
-            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, nullptr, st, L, ci + 2, bb));
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, B, nullptr, st, L));          // out -> bc
+            TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, Bl, nullptr, st, L, ci + 2, bb));
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bc, bb, 1, Bl, nullptr, st, L));         // out -> bc
             ci += 3;
-            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, B, nullptr, st, L));         // t
+            TRY(run_conv(ctx, r, ci, bc, S, 1, ba, nullptr, 1, Bl, nullptr, st, L));        // t
             float* pool = (L == 3) ? r->feats + (size_t)feat_row * kFeat : nullptr;
-            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, B, pool, st, L));             // out -> bb (+ avg-pool)
+            TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, bc, 1, Bl, pool, st, L));            // out -> bb (+ avg-pool)
             ci += 2;
             x = bb;
         }

@@ -856,7 +856,7 @@ def test_single_view_fit_warm_started_from_its_own_record_continues_the_trajecto
 
 # ---------------------------------------------------------------- regressor (a2-a4)
 @pytest.mark.parametrize('precision', ['bf16', 'f16'])
-# 3: ragged, layer4 falls back to the ring kernel; 6: layer4 in whole 128-pixel tiles (two 8 x 8 images each) that are no whole
+# 3: an odd batch: layer4 (tiles = pairs of 8 x 8 images) runs on B + 1 crops, the extra one never read; 6: layer4 in whole 128-pixel tiles (two 8 x 8 images each) that are no whole
 # 256-pixel ones, as for the 22-player frame, and the stem's band height by cost; 8: every patch kernel incl. the 8x8 one; 32: the
 # BENCHMARK plan (all 32 crops checked); '32-contended': the same while a second regressor keeps the chip busy from another stream,
 # so the persistent / dynamically scheduled kernels are checked against the oracle under CU contention, not only against themselves
