@@ -357,7 +357,7 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     if (conv_wres_supported(a)) {                      // layer1: 3x3 / 1, 64 -> 64, weights resident in LDS
         ++r->next_counter;
         ProfScope ps(ctx, kKConvWres, st, true);
-        return launch_conv_wres(a, ctx->num_cus / r->wres_cu_div, st);
+        return launch_conv_wres(a, r->wres_cu_div >= 32 ? r->wres_cu_div : ctx->num_cus / r->wres_cu_div, st);      // (>= 32: an explicit workgroup count, experiments)
     }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 128 pixels
         if (((r->p4_layers >> L) & 1) && conv_p4_supported(a)) {       // layer2; layer3 in plan "throughput": no K split, producer waves
@@ -715,7 +715,8 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             r->p4_cu_div = value;
             return SPSP_OK;
         case SPSP_DEBUG_PLAN_WRES_CUS:
-            SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8 || value == 16, "spsp_regressor_debug: layer1 on 1 / %d of the CUs", value);
+            SPSP_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || (value >= 32 && value <= 256 && value % 8 == 0),
+                         "spsp_regressor_debug: layer1 on 1 / %d of the CUs (or 32 .. 256 workgroups, a multiple of 8)", value);
             r->wres_cu_div = value;
             return SPSP_OK;
         case SPSP_DEBUG_PLAN_STEM_BAND:

@@ -32,10 +32,11 @@ prod = lambda *layers: [(_abi.DEBUG_PLAN_PATCH_PRODUCER, L * 10 + 1) for L in la
 W, SB, P4, P4C, S2C = _abi.DEBUG_PLAN_WRES_CUS, _abi.DEBUG_PLAN_STEM_BAND, _abi.DEBUG_PLAN_P4, _abi.DEBUG_PLAN_P4_CUS, _abi.DEBUG_PLAN_S2RS_CUS
 base = [(_abi.DEBUG_PLAN_S2, 1), (_abi.DEBUG_PLAN_LAYER4_CHANNELS, 64)]
 PLANS = {      # (PlayerPipeline puts its slots in plan "throughput": the hooks below override single choices of it)
+    'plan "throughput" (layer1 on 64 workgroups)': base + [(P4, 6), (W, 4), (SB, 64), (S2C, 2)],
+    'layer1 on 48 workgroups': base + [(P4, 6), (W, 48), (SB, 64), (S2C, 2)],
+    'layer1 on 80 workgroups': base + [(P4, 6), (W, 80), (SB, 64), (S2C, 2)],
+    'layer1 on 96 workgroups': base + [(P4, 6), (W, 96), (SB, 64), (S2C, 2)],
     'chip-filling grids, layer2 / layer3 on conv_patch (round 3)': base + [(P4, 0), (W, 1), (SB, 0), (S2C, 1)],
-    'plan "throughput": conv_p4, layer1 on 1/4 of the CUs, stem bands of 64 rows, layer2.0 two tiles per workgroup': base + [(P4, 6), (W, 4), (SB, 64), (S2C, 1)],
-    'the same with layer2.0 four tiles per workgroup': base + [(P4, 6), (W, 4), (SB, 64), (S2C, 2)],
-    'the same with layer2.0 eight tiles per workgroup': base + [(P4, 6), (W, 4), (SB, 64), (S2C, 4)],
 }
 if os.environ.get('AB_OLD_PLANS'):
     PLANS = {
