@@ -187,7 +187,7 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
  * SPSP_PLAN_LATENCY (a fresh handle's plan): for ONE batch in flight -- every kernel's grid fills the chip.
  * SPSP_PLAN_THROUGHPUT: for several batches in flight on different streams (four pipeline slots) -- the kernels with the least CU
  * time per batch: the persistent kernels run NARROW (layer1 on a quarter of the CUs with eight tiles per resident weight set,
- * the stem in bands of 64 rows, layer2.0 four tiles per workgroup), layer3 one image per workgroup without the K split (conv_p4.hip, half the chip), layer4 in
+ * the stem in bands of 32 rows, layer2.0 four tiles per workgroup), layer3 one image per workgroup without the K split (conv_p4.hip, half the chip), layer4 in
  * 64-channel blocks (half the chip).  One batch alone takes ~0.2 ms longer this way; four in flight finish 6-8 % more players/s. */
 #define SPSP_PLAN_THROUGHPUT 0
 #define SPSP_PLAN_LATENCY    1

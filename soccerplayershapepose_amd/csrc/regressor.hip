@@ -314,7 +314,7 @@ struct spsp_regressor {
     // Plan "throughput": with four batches in flight on four streams a kernel that fills the chip for a short time competes with
     // three others for every CU, and pays its prologue (layer1: 72 KB of weights + the first patch per workgroup, a third of its
     // run time at two tiles per workgroup) once per workgroup.  Persistent kernels are therefore launched NARROW there: layer1 on a
-    // quarter of the CUs (8 tiles per resident weight set), the stem in bands of 64 conv rows (64 workgroups at B = 32).  Four-slot
+    // quarter of the CUs (8 tiles per resident weight set), the stem in bands of 32 conv rows (128 workgroups at B = 32).  Four-slot
     // pipeline, same box: 120.8 k -> 127.6 k players/s with layer1 on 1/4 (1/8: 124.3 k, 1/16: 106.9 k), 128.6 k with the stem bands
     // as well (bands of 128 rows = 32 workgroups: 110.9 k) -- tools/ab_pipeline.py, profiles/r04_ab_narrow.txt.  One batch in flight
     // pays for it (layer1 61 -> ~240 us): plan "latency" keeps the chip-filling grids.  Round 4, later: layer2.0 (conv_s2rs: 80 KB of
@@ -694,7 +694,7 @@ int spsp_regressor_set_plan(spsp_regressor* r, int plan) {
     r->patch_nch[3] = plan == SPSP_PLAN_LATENCY ? 32 : 64;
     r->p4_layers = plan == SPSP_PLAN_LATENCY ? 2 : 6;
     r->wres_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 4;
-    r->stem_band = plan == SPSP_PLAN_LATENCY ? 0 : 64;
+    r->stem_band = plan == SPSP_PLAN_LATENCY ? 0 : 32;      // (bands of 32 and of 64 rows tie or 32 wins by 1-1.5 %: profiles/r04_ab_narrow.txt)
     r->s2rs_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 2;      // layer2.0: four tiles per resident weight set (128 workgroups at B = 32)
     return SPSP_OK;
 }
