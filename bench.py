@@ -434,9 +434,10 @@ def main():
             torch.cuda.synchronize()
         r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
         return read_profile(iso_steps)
+    pipe_plan = 'throughput' if len(pipe.slots) >= 2 else 'latency'      # (what PlayerPipeline selected for its slots)
     kernels_iso_tp = isolated_pass('throughput')
     kernels_iso = isolated_pass('latency')
-    reg.set_plan('throughput')
+    reg.set_plan(pipe_plan)
     pipe._next = 0
     # dominant kernel = the MFMA conv kernel with the largest time per step among those whose launches all do the same
     # algorithmic work (the library names it: spsp_profile_kernel_flop_per_crop > 0)
@@ -550,7 +551,7 @@ def main():
                 exchange.all_gather(rec, FRAME_PLAYERS)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t0)
-    reg.set_plan('throughput')
+    reg.set_plan(pipe_plan)
     pipe._next = 0
     lat_t = torch.tensor(sorted(lat[5:])[len(lat[5:]) // 2], dtype=torch.float64, device=dev)
     if use_dist:
@@ -643,6 +644,7 @@ def main():
                        'crops_per_gpu': B, 'global_batch': world * B, 'fit_iters': FIT_ITERS, 'fit_variant': args.fit,
                        'parallelism': f'dp{world}', 'input_layout': f'NHWC {args.precision} [262,264,18] resident in HBM',
                        'pipeline_slots': max(1, args.depth), 'hip_graphs': bool(args.graphs), 'input_batches_rotated': n_inputs,
+                       'regressor_plan': reg.plan + (' + hooks ' + args.plan_hooks if args.plan_hooks else ''),
                        'proxy_built_on_gpu': bool(args.from_detections),
                        'exchange': (exchange.describe() if exchange else None)},
             # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
