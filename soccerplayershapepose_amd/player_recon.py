@@ -521,6 +521,11 @@ class PlayerPipeline:
         self.device = torch.device(device)
         self.use_graphs = bool(use_graphs)
         self.slots = []
+        if depth >= 2 and int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) < depth + 1:
+            import warnings
+            warnings.warn(f'PlayerPipeline: {depth} slots + the caller\'s stream on GPU_MAX_HW_QUEUES='
+                          f'{os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")} hardware queues: slots will share a queue and '
+                          f'serialise (measured: 87 k instead of 129 k players/s at four slots).  Set GPU_MAX_HW_QUEUES=8 before the first GPU call.')
         if streams is not None and len(streams) != depth:
             raise ValueError(f'{len(streams)} streams for {depth} slots')
         for i in range(depth):
