@@ -70,9 +70,10 @@ int         spsp_profile_select(spsp_ctx* ctx, int kernel_id);
 int         spsp_profile_num_kernels(void);
 const char* spsp_profile_kernel_name(int id);
 /* Algorithmic FLOPs one launch of kernel `id` does per crop, when every launch of it does the same work (the MFMA
- * convolutions; 0 for everything else), and whether the default batch-32 plan launches the kernel. */
+ * convolutions; 0 for everything else), and whether launch plan `plan` (SPSP_PLAN_THROUGHPUT | SPSP_PLAN_LATENCY, below) launches
+ * the kernel for a batch of 32. */
 double      spsp_profile_kernel_flop_per_crop(int id);
-int         spsp_profile_kernel_in_default_plan(int id);
+int         spsp_profile_kernel_in_plan(int id, int plan);
 int         spsp_profile_read(spsp_ctx* ctx, int n, double* total_ms, int* launches);
 /* the same, and per kernel the workgroups of its single-launch scopes summed (0 for the others): launches narrower than the chip
  * (plan "throughput") are priced against the CUs they occupy */
@@ -179,7 +180,13 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
  *   backbone: proxy crops -> pooled features, rows [feat_row, feat_row + B) of the handle's feature buffer (max_batch rows);
  *   ief:      the iterative-error-feedback MLP on rows [0, B) of that buffer -> cam / pose6d / betas (feats optional).
  * Several backbone calls with different feat_row, then ONE ief over all their rows: how spsp_pipeline_group batches the
- * latency-bound tail of the path (IEF -> fit -> SMPL) over consecutive batches while the convolutions keep their batch. */
+ * latency-bound tail of the path (IEF -> fit -> SMPL) over consecutive batches while the convolutions keep their batch.
+ * The fused IEF kernel's grid-wide hand-offs count on eight monotonic counters of the handle that must start at zero: a backbone
+ * call leaves them zeroed (its stem kernel does it), an ief call uses them up.  spsp_regressor_ief tracks that on the handle (host
+ * side) and, when no backbone call has run since the last ief -- ief twice on the same features, ief on a fresh handle -- zeroes
+ * them itself with a memset on `stream` first; both orders give the same results.  (Under stream capture the choice is made when
+ * the call is captured: capture backbone + ief together, or an ief alone that is preceded by a backbone call at capture time
+ * only if every replay is.) */
 int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, int feat_row, void* stream);
 int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, float* pose6d, float* betas, float* feats, void* stream);
 /* Launch plan of the handle's forwards (same results up to the fp32 summation order of layer3; takes effect at the next forward,
@@ -209,11 +216,17 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_PLAN_PATCH_PRODUCER 5   /* value = layer (1..3) * 10 + (0 | 1): four DMA-only producer waves in that stage's patch kernel */
 #define SPSP_DEBUG_PLAN_S2RS_CUS 11        /* conv_s2rs: tiles per workgroup as for a chip of 1 / value of the CUs (1, 2, 4, 8: 2, 4, 8 tiles at B = 32) */
 #define SPSP_DEBUG_PLAN_P4_CUS 10          /* conv_p4's workgroups: at most 1 / value of the CUs (1, 2, 4, 8), persistent over the tiles beyond */
-#define SPSP_DEBUG_PLAN_STEM_BAND 9        /* conv rows per workgroup of the stem kernel (0: grid-filling default, 32, 64, 128 = one workgroup per crop) */
+#define SPSP_DEBUG_PLAN_STEM_BAND 9        /* conv rows per workgroup of the stem kernel (0: grid-filling default, 16, 32, 64; capped where fewer than a quarter of the CUs would get a workgroup) */
 #define SPSP_DEBUG_PLAN_WRES_CUS 8         /* layer1's persistent workgroups on 1 / value of the CUs (1, 2, 4, 8, 16): more tiles per resident weight set */
 #define SPSP_DEBUG_PLAN_P4 7               /* bit L set: the 3x3 stride-1 convs of layer L+1 on conv_p4.hip (256-pixel tiles, no K split, producer waves); default: bit 1 = layer2 */
 #define SPSP_DEBUG_PLAN_S2RS 6             /* 0: layer2.0's stride-2 pair on the streaming kernel of the other stages, 1 (default): weights stationary in registers */
 int spsp_regressor_debug(spsp_regressor* r, int what, int value);
+/* Test hook of an SMPL handle.  SPSP_DEBUG_FIT_SCHEDULE: which form of the reprojection-fit kernel spsp_fit / spsp_pipeline launch on
+ * this handle -- 2 (default) the current schedule, 1 the ten-barrier schedule of rounds 1-3 (tree walks), 0 the level-by-level sweeps
+ * (what a model with a tree other than SMPL's always gets).  Same algorithm; A/B switch of tests and tools, never read from the
+ * environment. */
+#define SPSP_DEBUG_FIT_SCHEDULE 1
+int spsp_smpl_debug(spsp_smpl* s, int what, int value);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
  * (1 maxpool, 2..5 layer1..layer4; stage 0 -- conv1+relu -- no longer exists as a map since conv1 and the max-pool are one
  * kernel: SPSP_EINVAL) of the LAST forward as fp32 NCHW into `out`. */

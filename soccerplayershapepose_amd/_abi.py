@@ -25,6 +25,7 @@ PROXY_NCHW_F32, PROXY_NATIVE = 0, 1
 PRECISION_BF16, PRECISION_F16 = 0, 1
 SIL_U8, SIL_F32 = 0, 1
 DEBUG_IEF_STALL, DEBUG_PLAN_S2, DEBUG_PLAN_LAYER4_CHANNELS, DEBUG_PLAN_PATCH, DEBUG_PLAN_PATCH_PRODUCER, DEBUG_PLAN_S2RS, DEBUG_PLAN_P4, DEBUG_PLAN_WRES_CUS, DEBUG_PLAN_STEM_BAND, DEBUG_PLAN_P4_CUS, DEBUG_PLAN_S2RS_CUS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+DEBUG_FIT_SCHEDULE = 1          # spsp_smpl_debug
 REGRESSOR_MAX_BATCH, REGRESSOR_MAX_CONCURRENT = 256, 8
 PLAN_THROUGHPUT, PLAN_LATENCY = 0, 1
 
@@ -124,7 +125,7 @@ _PROTOS = {
     'spsp_profile_num_kernels': (C.c_int, []),
     'spsp_profile_kernel_name': (C.c_char_p, [C.c_int]),
     'spsp_profile_kernel_flop_per_crop': (C.c_double, [C.c_int]),
-    'spsp_profile_kernel_in_default_plan': (C.c_int, [C.c_int]),
+    'spsp_profile_kernel_in_plan': (C.c_int, [C.c_int, C.c_int]),
     'spsp_profile_timeline': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     'spsp_profile_read': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -162,6 +163,7 @@ _PROTOS = {
     'spsp_unpack_record': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     'spsp_smpl_load': (C.c_int, [_vp, C.POINTER(SmplArrays), C.c_int, C.POINTER(_vp)]),
     'spsp_smpl_free': (None, [_vp]),
+    'spsp_smpl_debug': (C.c_int, [_vp, C.c_int, C.c_int]),
     'spsp_smpl_forward': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     'spsp_fit_config_default': (None, [C.POINTER(FitConfig), C.c_int]),
     'spsp_fit': (C.c_int, [_vp, _vp, C.POINTER(FitConfig), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),

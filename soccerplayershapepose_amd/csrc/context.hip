@@ -41,21 +41,25 @@ void spsp_destroy(spsp_ctx* ctx) {
 // One row per profiled kernel id (common.hpp, KernelId): the name bench.py / profiles/collect_traffic.py match against
 // rocprofv3's kernel names (template arguments after the ones listed are element type / buffering flags), the
 // algorithmic FLOPs ONE launch does per crop when every launch of the kernel does the same work (0 otherwise: not a
-// roofline candidate), and whether the default batch-32 plan launches it.
-struct KernelRow { const char* name; double flop_per_crop; int in_default_plan; };
+// roofline candidate), and which launch plans of a batch of 32 launch it: bit SPSP_PLAN_THROUGHPUT (what PlayerPipeline gives its
+// slots; layer3 on conv_p4) | bit SPSP_PLAN_LATENCY (a fresh handle's plan; layer3 on conv_patch<false>).
+struct KernelRow { const char* name; double flop_per_crop; int plans; };
+static const int kTP = 1 << SPSP_PLAN_THROUGHPUT, kLT = 1 << SPSP_PLAN_LATENCY, kBoth = kTP | kLT;
 static const double kFlopConv1 = 2.0 * 924844032.0, kFlop3x3 = 2.0 * 150994944.0;
 static const double kFlopS2 = 2.0 * (75497472.0 + 8388608.0);     // a 3x3 / 2 conv + its 1x1 / 2 downsample
 static const KernelRow kKernels[spsp::kKNumKernels] = {
-    {"conv1_pool_kernel", kFlopConv1, 1}, {"conv3x3_wres_kernel", kFlop3x3, 1},
-    {"conv3x3_patch_kernel<false>", kFlop3x3, 0}, {"conv3x3_patch_kernel<true>", kFlop3x3, 1}, {"conv_ring_kernel", 0, 0},
-    {"ief_fused_kernel", 0, 1}, {"ief_init_only_kernel", 0, 0}, {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0},
-    {"rot6d_kernel", 0, 0}, {"fit_kernel2", 0, 1}, {"smpl_chain_kernel", 0, 0}, {"smpl_skin_kernel", 0, 1},
-    {"smpl_extra_joints_kernel", 0, 1}, {"relate_project_kernel+relate_attend_kernel", 0, 0}, {"conv3x3s2_kernel", kFlopS2, 1}, {"conv3x3_p4_kernel", kFlop3x3, 1}};
+    {"conv1_pool_kernel", kFlopConv1, kBoth}, {"conv3x3_wres_kernel", kFlop3x3, kBoth},
+    {"conv3x3_patch_kernel<false>", kFlop3x3, kLT}, {"conv3x3_patch_kernel<true>", kFlop3x3, kBoth}, {"conv_ring_kernel", 0, 0},
+    {"ief_fused_kernel", 0, kBoth}, {"ief_init_only_kernel", 0, 0}, {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0},
+    {"rot6d_kernel", 0, 0}, {"fit_kernel2", 0, kBoth}, {"smpl_chain_kernel", 0, 0}, {"smpl_skin_kernel", 0, kBoth},
+    {"smpl_extra_joints_kernel", 0, kBoth}, {"relate_project_kernel+relate_attend_kernel", 0, 0}, {"conv3x3s2_kernel", kFlopS2, kBoth}, {"conv3x3_p4_kernel", kFlop3x3, kBoth}};
 
 int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
 const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].name : nullptr; }
 double spsp_profile_kernel_flop_per_crop(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].flop_per_crop : 0.0; }
-int spsp_profile_kernel_in_default_plan(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].in_default_plan : 0; }
+int spsp_profile_kernel_in_plan(int id, int plan) {
+    return (id >= 0 && id < spsp::kKNumKernels && (plan == SPSP_PLAN_THROUGHPUT || plan == SPSP_PLAN_LATENCY)) ? (kKernels[id].plans >> plan) & 1 : 0;
+}
 
 int spsp_profile_enable(spsp_ctx* ctx, int on) {
     SPSP_REQUIRE(ctx, "spsp_profile_enable: NULL ctx");

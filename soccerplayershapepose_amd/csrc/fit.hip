@@ -250,6 +250,17 @@ void spsp_fit_config_default(spsp_fit_config* c, int variant) {
     }
 }
 
+int spsp_smpl_debug(spsp_smpl* s, int what, int value) {
+    SPSP_REQUIRE(s, "spsp_smpl_debug: NULL handle");
+    if (what == SPSP_DEBUG_FIT_SCHEDULE) {
+        SPSP_REQUIRE(value >= 0 && value <= 2, "spsp_smpl_debug: fit schedule %d (0 level sweeps, 1 ten-barrier walks, 2 default)", value);
+        s->fit_schedule = value;
+        return SPSP_OK;
+    }
+    spsp::set_error("spsp_smpl_debug: unknown hook %d", what);
+    return SPSP_EINVAL;
+}
+
 int spsp_fit(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R, float* betas, float* cam,
              const float* joints2d, int B, float* loss_hist, float* l2e_hist, void* stream) {
     return spsp_fit_trajectory(ctx, s, cfg, R, betas, cam, joints2d, B, loss_hist, l2e_hist, nullptr, stream);
@@ -297,13 +308,12 @@ int fit_launch(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R
 #define SPSP_FIT_LAUNCH(WALK)                                                                                                        \
     launch_kernel(&fit_kernel<WALK>, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,  \
                   s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg)
-    // (the level sweeps remain for models whose tree is not SMPL's; the variables are the A/B switches of tests and tools:
-    //  SPSP_FIT_SCHEDULE=1 = the ten-barrier schedule of rounds 1-3 with the walks, SPSP_FIT_LEVEL_SWEEPS = with the level sweeps)
-    const char* sched = getenv("SPSP_FIT_SCHEDULE");
-    if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS") && !(sched && sched[0] == '1'))
+    // (the level sweeps remain for models whose tree is not SMPL's; the older schedules are the A/B switch of tests and tools:
+    //  spsp_smpl_debug(s, SPSP_DEBUG_FIT_SCHEDULE, 1) = the ten-barrier schedule of rounds 1-3 with the walks, 0 = with the level sweeps)
+    if (s->walk_ok && s->fit_schedule == 2)
         launch_kernel(&fit_kernel2, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,
                       s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg);
-    else if (s->walk_ok && !getenv("SPSP_FIT_LEVEL_SWEEPS")) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
+    else if (s->walk_ok && s->fit_schedule == 1) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
 #undef SPSP_FIT_LAUNCH
     if (dbg) {
         unsigned long long h[16];

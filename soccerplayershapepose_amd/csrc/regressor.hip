@@ -321,9 +321,13 @@ struct spsp_regressor {
     // weights in registers per workgroup) with four tiles per workgroup instead of two: +1.6 % (eight: the same).
     int s2rs_cu_div = 1;                // conv_s2rs: tiles per resident weight set as if the chip had num_cus / this CUs (2 -> 4 -> 8 tiles)
     int p4_cu_div = 1;                  // conv_p4's workgroups: at most num_cus / this (persistent over the tiles beyond)
-    int stem_band = 0;                  // conv rows per stem workgroup when coarser than the grid-filling default (32, 64, 128: the whole image)
+    int stem_band = 0;                  // conv rows per stem workgroup when coarser than the grid-filling default (32, 64)
     int wres_cu_div = 1;                // layer1's persistent workgroups: num_cus / this (2: twice the tiles per workgroup, half the chip)
     bool use_s2rs = true;               // layer2.0 on conv_s2rs.hip (weights stationary in registers); off: conv_s2.hip like the other two
+    // The fused IEF's arrival counters are monotonic and must start at zero.  A backbone call zeroes them (the stem kernel's first
+    // workgroup does, with the tile-scheduler words); an IEF call uses them up.  spsp_regressor_ief on a handle whose counters are
+    // not fresh (IEF run twice on the same features, IEF before any backbone) zeroes its eight lines itself with a memset node.
+    bool ief_counters_fresh = false;
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
 
@@ -625,6 +629,7 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
         r->stage_ptr[2 + L] = x;
     }
     r->last_B = B;
+    r->ief_counters_fresh = true;
     SPSP_HIP_CHECK(hipGetLastError());
 #undef TRY
     return SPSP_OK;
@@ -646,6 +651,10 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
         ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
         ia.h1 = r->h1; ia.s = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
         ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed by the backbone call)
+        // ... or here, when no backbone call has run since the last IEF on this handle: with used-up counters every hand-off
+        // of the launch would pass at once and the kernel would read hidden vectors that are not written yet
+        if (!r->ief_counters_fresh) SPSP_HIP_CHECK(hipMemsetAsync(ia.counters, 0, 8 * 32 * sizeof(unsigned int), st));
+        r->ief_counters_fresh = false;
         ia.B = B; ia.iters = r->ief_iters;
         ia.err = r->err_dev;
         ia.spin_limit = 1u << 22;
@@ -720,7 +729,8 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             r->wres_cu_div = value;
             return SPSP_OK;
         case SPSP_DEBUG_PLAN_STEM_BAND:
-            SPSP_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64 || value == 128, "spsp_regressor_debug: stem bands of %d rows", value);
+            // (bands stop growing where fewer than a quarter of the CUs would get a workgroup -- launch_conv_stem: 64 rows at B = 32)
+            SPSP_REQUIRE(value == 0 || value == 16 || value == 32 || value == 64, "spsp_regressor_debug: stem bands of %d rows", value);
             r->stem_band = value;
             return SPSP_OK;
         case SPSP_DEBUG_PLAN_LAYER4_CHANNELS:

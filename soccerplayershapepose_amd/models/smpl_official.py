@@ -94,6 +94,10 @@ class SMPL:
             self._load(rt.get())
         return self._handle
 
+    def debug(self, what, value):
+        """Test hook (`spsp_smpl_debug`): e.g. `_abi.DEBUG_FIT_SCHEDULE`, 2 | 1 | 0 = which form of the fit kernel runs on this handle."""
+        self._rt.check(self._rt.lib.spsp_smpl_debug(self.handle, what, value), 'spsp_smpl_debug')
+
     # -- forward ------------------------------------------------------------------------------------
     def full_pose_from(self, body_pose, global_orient, B, device):
         eye = None

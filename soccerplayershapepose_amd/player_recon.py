@@ -521,11 +521,12 @@ class PlayerPipeline:
         self.device = torch.device(device)
         self.use_graphs = bool(use_graphs)
         self.slots = []
-        if depth >= 2 and int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) < depth + 1:
+        from . import hw_queues
+        if depth >= 2 and hw_queues() < depth + 1:
             import warnings
-            warnings.warn(f'PlayerPipeline: {depth} slots + the caller\'s stream on GPU_MAX_HW_QUEUES='
-                          f'{os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")} hardware queues: slots will share a queue and '
-                          f'serialise (measured: 87 k instead of 129 k players/s at four slots).  Set GPU_MAX_HW_QUEUES=8 before the first GPU call.')
+            warnings.warn(f'PlayerPipeline: {depth} slots + the caller\'s stream on {hw_queues()} hardware queues (GPU_MAX_HW_QUEUES as the GPU '
+                          f'runtime saw it when it started): slots will share a queue and serialise (measured: 87 k instead of 129 k '
+                          f'players/s at four slots).  Set GPU_MAX_HW_QUEUES=8 before the first GPU call of the process.', RuntimeWarning)
         if streams is not None and len(streams) != depth:
             raise ValueError(f'{len(streams)} streams for {depth} slots')
         for i in range(depth):

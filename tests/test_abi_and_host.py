@@ -56,21 +56,21 @@ def test_profile_kernel_names_and_native_layout_size():
     # roofline candidates (every launch does the same algorithmic work) are MFMA convolutions of the default plan or fallbacks
     cands = [names[i] for i in range(n) if lib.spsp_profile_kernel_flop_per_crop(i) > 0]
     assert cands and all(k.startswith('conv') for k in cands)
-    assert lib.spsp_profile_kernel_flop_per_crop(-1) == 0 and lib.spsp_profile_kernel_in_default_plan(n) == 0
+    assert lib.spsp_profile_kernel_flop_per_crop(-1) == 0 and lib.spsp_profile_kernel_in_plan(n, _abi.PLAN_LATENCY) == 0
 
 
-def test_every_default_plan_kernel_resolves_in_the_committed_traffic_table():
+def test_every_kernel_of_both_launch_plans_resolves_in_the_committed_traffic_table():
     """bench.py's roofline.traffic is profiles/hbm_traffic.json[<dominant kernel name>]: both sides take the kernel names
-    from the library's own table (profiles/collect_traffic.py maps rocprofv3's names onto it), so every kernel the
-    default batch-32 plan launches -- every possible dominant kernel in particular -- must be a key of the file."""
+    from the library's own table (profiles/collect_traffic.py maps rocprofv3's names onto it), so every kernel either
+    batch-32 launch plan launches -- every possible dominant kernel in particular -- must be a key of the file."""
     import json
     lib = _abi.load()
     table = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
     for i in range(lib.spsp_profile_num_kernels()):
-        if not lib.spsp_profile_kernel_in_default_plan(i):
+        if not (lib.spsp_profile_kernel_in_plan(i, _abi.PLAN_LATENCY) or lib.spsp_profile_kernel_in_plan(i, _abi.PLAN_THROUGHPUT)):
             continue
         for name in lib.spsp_profile_kernel_name(i).decode().split('+'):
-            assert name in table, f'{name} (default plan) has no entry in profiles/hbm_traffic.json'
+            assert name in table, f'{name} (launch plans) has no entry in profiles/hbm_traffic.json'
             assert table[name]['hbm_bytes_per_launch'] > 0
 
 
@@ -211,3 +211,26 @@ def test_conv_wres_tile_id_agpr_is_untouched_while_its_atomic_is_in_flight():
             else:
                 raise AssertionError(f'{reg}: the atomic\'s result is never read')
     assert checked >= len(kernels)
+
+
+def test_hardware_queue_setting_is_reported_as_the_runtime_saw_it():
+    """the package sets GPU_MAX_HW_QUEUES=8 at import, which only works before the GPU runtime starts.  `hw_queues()`
+    reports what the runtime can have seen (a non-integer value reads as the runtime's default, never raises), and an import into a
+    process whose runtime is already up without the variable warns at once."""
+    import subprocess, sys
+    code = 'import soccerplayershapepose_amd as p; print(p.hw_queues())'
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    run = lambda e: subprocess.run([sys.executable, '-c', code], env=e, cwd=ROOT, capture_output=True, text=True)
+    assert run(env).stdout.strip() == '8'
+    assert run(dict(env, GPU_MAX_HW_QUEUES='6')).stdout.strip() == '6'
+    assert run(dict(env, GPU_MAX_HW_QUEUES='many')).stdout.strip() == '4'
+    # the runtime already up (simulated: no GPU here): the variable is NOT set behind its back, and the import warns
+    fake = ('import sys, types, warnings\n'
+            't = types.ModuleType("torch"); t.cuda = types.SimpleNamespace(is_initialized=lambda: True); sys.modules["torch"] = t\n'
+            'with warnings.catch_warnings(record=True) as w:\n'
+            '    warnings.simplefilter("always")\n'
+            '    import soccerplayershapepose_amd as p\n'
+            'import os\n'
+            'print(p.hw_queues(), os.environ.get("GPU_MAX_HW_QUEUES"), len([x for x in w if "GPU_MAX_HW_QUEUES" in str(x.message)]))')
+    out = subprocess.run([sys.executable, '-c', fake], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert out.stdout.strip() == '4 None 1', (out.stdout, out.stderr)

@@ -366,7 +366,7 @@ def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
             native = reg.pack(torch.from_numpy(x).to(dev))
             got = []
             r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_P4, 6), 'debug')
-            for div, band, p4div in ((1, 0, 1), (4, 64, 4), (2, 32, 2), (16, 128, 8)):
+            for div, band, p4div in ((1, 0, 1), (4, 64, 4), (2, 32, 2), (16, 16, 8)):
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_WRES_CUS, div), 'debug')
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM_BAND, band), 'debug')
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_P4_CUS, p4div), 'debug')
@@ -385,10 +385,11 @@ def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
                 assert all(float((a - b).abs().max()) <= (1e-4 if prec == 'f16' else 1e-3) for a, b in zip(lat[:-1], thr[:-1]))
 
 
-def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, monkeypatch):
+def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev):
     """The fit's kinematic chain and reverse sweep run as register-resident walks over quads of lanes (csrc/fit_core.hpp:
     fit_chain_walk, fit_reverse_walk_a / _b -- DPP row broadcasts in place of eight LDS hand-offs per sweep); the level sweeps
-    they replaced remain for models with another tree and are selected by SPSP_FIT_LEVEL_SWEEPS (read at every launch).  Same
+    they replaced remain for models with another tree and are selected by `spsp_smpl_debug(SPSP_DEBUG_FIT_SCHEDULE, 0)`; 1 = the walks
+    in the same ten-barrier schedule.  Same
     operations in the same order: every iterate of both variants, all 229 parameters of 7 players over 50 iterations, bit for bit."""
     from soccerplayershapepose_amd.player_recon import fit_players
     B = 7
@@ -396,17 +397,16 @@ def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, mon
     out = smpl_gpu(body_pose=torch.from_numpy(R[:, 1:]).to(dev), global_orient=torch.from_numpy(R[:, :1]).to(dev), betas=torch.from_numpy(b).to(dev))
     tgt = S.fit_targets_from_joints(out.joints.cpu().numpy(), cam * np.array([1.1, 1, 1], np.float32), seed=5)
     runs = []
-    for sweeps in (False, True):
-        if sweeps:
-            monkeypatch.setenv('SPSP_FIT_LEVEL_SWEEPS', '1')
-        else:
-            monkeypatch.delenv('SPSP_FIT_LEVEL_SWEEPS', raising=False)
-        for variant in (0, 1):
-            Rg, bg, cg = (torch.from_numpy(a).to(dev).contiguous() for a in (R, b, cam))
-            hist = fit_players(smpl_gpu, Rg, bg, cg, tgt, variant=variant, iters=50, return_trajectory=True)
-            torch.cuda.synchronize()
-            runs.append([Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist])
-    monkeypatch.delenv('SPSP_FIT_LEVEL_SWEEPS', raising=False)
+    try:
+        for sched in (1, 0):
+            smpl_gpu.debug(_abi.DEBUG_FIT_SCHEDULE, sched)
+            for variant in (0, 1):
+                Rg, bg, cg = (torch.from_numpy(a).to(dev).contiguous() for a in (R, b, cam))
+                hist = fit_players(smpl_gpu, Rg, bg, cg, tgt, variant=variant, iters=50, return_trajectory=True)
+                torch.cuda.synchronize()
+                runs.append([Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist])
+    finally:
+        smpl_gpu.debug(_abi.DEBUG_FIT_SCHEDULE, 2)
     for walk, level in ((runs[0], runs[2]), (runs[1], runs[3])):
         assert len(walk) == len(level) == 6
         for x, y in zip(walk, level):
@@ -414,10 +414,10 @@ def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev, mon
     assert not torch.equal(runs[1][0], torch.from_numpy(R).to(dev))         # (the fit did move the pose)
 
 
-def test_fit_schedule_v2_is_bit_identical_to_the_ten_barrier_schedule(smpl_gpu, dev, monkeypatch):
+def test_fit_schedule_v2_is_bit_identical_to_the_ten_barrier_schedule(smpl_gpu, dev):
     """csrc/fit.hip fit_kernel2 (the default since round 4: eight barriers per iteration, Adam steps in the lanes that compute the
     gradients, waves 1 and 3 working beside wave 0's tree walks -- csrc/fit_core.hpp "round 4") against the schedule of rounds 1-3
-    (`SPSP_FIT_SCHEDULE=1`, read at every launch).  The same operations produce every value in the same order: every iterate of
+    (`spsp_smpl_debug(SPSP_DEBUG_FIT_SCHEDULE, 1)`).  The same operations produce every value in the same order: every iterate of
     both fit variants and both select modes, the loss / l2e histories and the results, 9 players over 50 iterations, bit for bit."""
     from soccerplayershapepose_amd.player_recon import fit_players
     B = 9
@@ -425,18 +425,17 @@ def test_fit_schedule_v2_is_bit_identical_to_the_ten_barrier_schedule(smpl_gpu, 
     out = smpl_gpu(body_pose=torch.from_numpy(R[:, 1:]).to(dev), global_orient=torch.from_numpy(R[:, :1]).to(dev), betas=torch.from_numpy(b).to(dev))
     tgt = S.fit_targets_from_joints(out.joints.cpu().numpy(), cam * np.array([1.1, 1, 1], np.float32), seed=6)
     runs = {}
-    for sched in ('2', '1'):
-        if sched == '1':
-            monkeypatch.setenv('SPSP_FIT_SCHEDULE', '1')
-        else:
-            monkeypatch.delenv('SPSP_FIT_SCHEDULE', raising=False)
-        for variant in (0, 1):
-            for select in (_abi.FIT_SELECT_LAST, _abi.FIT_SELECT_BEST_L2E):
-                Rg, bg, cg = (torch.from_numpy(a).to(dev).contiguous() for a in (R, b, cam))
-                hist = fit_players(smpl_gpu, Rg, bg, cg, tgt, variant=variant, iters=50, return_trajectory=True, select_mode=select)
-                torch.cuda.synchronize()
-                runs[(sched, variant, select)] = [Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist]
-    monkeypatch.delenv('SPSP_FIT_SCHEDULE', raising=False)
+    try:
+        for sched in ('2', '1'):
+            smpl_gpu.debug(_abi.DEBUG_FIT_SCHEDULE, int(sched))
+            for variant in (0, 1):
+                for select in (_abi.FIT_SELECT_LAST, _abi.FIT_SELECT_BEST_L2E):
+                    Rg, bg, cg = (torch.from_numpy(a).to(dev).contiguous() for a in (R, b, cam))
+                    hist = fit_players(smpl_gpu, Rg, bg, cg, tgt, variant=variant, iters=50, return_trajectory=True, select_mode=select)
+                    torch.cuda.synchronize()
+                    runs[(sched, variant, select)] = [Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist]
+    finally:
+        smpl_gpu.debug(_abi.DEBUG_FIT_SCHEDULE, 2)
     for variant in (0, 1):
         for select in (_abi.FIT_SELECT_LAST, _abi.FIT_SELECT_BEST_L2E):
             new, old = runs[('2', variant, select)], runs[('1', variant, select)]
@@ -1140,6 +1139,30 @@ def test_ief_hand_off_time_out_is_reported_as_an_error_not_as_silent_nans(regres
     reg.check_status()
     assert all(torch.equal(a, b) for a, b in zip(good, again))
 
+
+
+def test_ief_called_twice_on_the_same_features_gives_the_same_answer(regressor_sd_np, dev):
+    """`spsp_regressor_ief` counts its grid-wide hand-offs on monotonic counters that a backbone call zeroes; run a
+    second time without a backbone in between, every hand-off of the launch used to pass at once (stale hidden vectors, silently
+    wrong cam / pose / betas, SPSP_OK).  The handle now tracks whether its counters are fresh and zeroes them itself when they are
+    not: backbone -> ief -> ief -> ief gives three identical answers, equal to `spsp_regressor_forward`'s, at B = 5 and B = 40
+    (two blocks of 32: two counter lines)."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=40, precision='f16').load_state_dict(regressor_sd_np).to(dev)
+    r = rt.get(dev)
+    for B in (5, 40):
+        x, _ = S.proxy_crops(B, seed=60 + B)
+        native = reg.pack(torch.from_numpy(x).to(dev))
+        want = [t.clone() for t in reg(native)]
+        torch.cuda.synchronize()
+        r.check(r.lib.spsp_regressor_backbone(r.ctx, reg.handle, rt.ptr(native), _abi.PROXY_NATIVE, B, 0, r.stream()), 'spsp_regressor_backbone')
+        for _ in range(3):
+            cam, pose, betas = (torch.full((B, n), float('nan'), device=dev) for n in (3, 144, 10))
+            r.check(r.lib.spsp_regressor_ief(r.ctx, reg.handle, B, rt.ptr(cam), rt.ptr(pose), rt.ptr(betas), None, r.stream()), 'spsp_regressor_ief')
+            torch.cuda.synchronize()
+            reg.check_status()
+            assert torch.equal(cam, want[0]) and torch.equal(pose, want[1]) and torch.equal(betas, want[2])
 
 
 def test_predict_3d_mirror(regressor_gpu, smpl_gpu, dev):

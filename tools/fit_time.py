@@ -4,19 +4,14 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from soccerplayershapepose_amd import synthetic as S
+from soccerplayershapepose_amd import _abi, synthetic as S
 from soccerplayershapepose_amd.models.smpl_official import SMPL
 from soccerplayershapepose_amd.player_recon import fit_players
 dev = torch.device('cuda', 0)
 for plan in ('v2', 'walks', 'level sweeps'):
-    os.environ.pop('SPSP_FIT_LEVEL_SWEEPS', None)
-    os.environ.pop('SPSP_FIT_SCHEDULE', None)
-    if plan == 'level sweeps':
-        os.environ['SPSP_FIT_LEVEL_SWEEPS'] = '1'
-    if plan == 'walks':
-        os.environ['SPSP_FIT_SCHEDULE'] = '1'
     for B in (32, 22):
         smpl = SMPL(S.smpl_model(seed=0), max_batch=32).to(dev)
+        smpl.debug(_abi.DEBUG_FIT_SCHEDULE, {'v2': 2, 'walks': 1, 'level sweeps': 0}[plan])
         R, b, cam = S.pose_params(B, seed=1)
         tgt = torch.rand(B, 17, 2, device=dev) * 512
         args = lambda: (torch.from_numpy(R).to(dev).contiguous(), torch.from_numpy(b).to(dev).contiguous(), torch.from_numpy(cam).to(dev).contiguous())
