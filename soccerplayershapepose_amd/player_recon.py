@@ -100,7 +100,8 @@ def single_view_optimization(smpl, body_pose, global_orient, betas, pred_cam_wp,
     full = torch.cat([rt.dev_f32(global_orient).reshape(B, 1, 3, 3), rt.dev_f32(body_pose).reshape(B, 23, 3, 3)], dim=1).contiguous()
     b = rt.dev_f32(betas).clone()
     cam = rt.dev_f32(pred_cam_wp).clone()
-    iters = interation if interation is not None else config.texture_single_opt_interation
+    # (the reference's default: `interation=player_recon_single_view_iteration` = 100, PR/player_recon.py:1051, S/global_var.py:75)
+    iters = interation if interation is not None else config.player_recon_single_view_iteration
     extra = {}
     if select_mode == FIT_SELECT_REFERENCE:
         if silhouette is None or renderer is None:

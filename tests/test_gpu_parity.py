@@ -11,6 +11,9 @@ import torch
 from soccerplayershapepose_amd import _abi, synthetic as S
 
 pytestmark = pytest.mark.gpu
+# SPSP_TEST_FULL=1: the oracle-heavy variants round 4 thinned for suite time (every player under the two-metric rules, two players
+# per multi-view case, the free-running oracle chain over all 30 frames of the clip) -- run once per round, profiles/r05_full_suite.txt
+FULL_ORACLE = bool(os.environ.get('SPSP_TEST_FULL'))
 
 
 def _oracle_fit_vertices(oracle_smpl, R, betas, tgt, cam, iters=50):
@@ -233,6 +236,34 @@ def test_fit_against_live_oracle_on_fresh_players_and_best_iterate(smpl_gpu, ora
                             select_mode=_abi.FIT_SELECT_BEST_L2E, return_history=True)
     assert abs(l2e.min().item() - res['best_l2e']) < 0.05
     np.testing.assert_allclose(cg.cpu().numpy()[0], res['best'][3].numpy()[0], atol=5e-3)
+
+
+def test_fit_variant_b_at_the_reference_default_of_100_iterations(smpl_gpu, oracle_smpl, smpl_model_np, dev):
+    """`single_view_optimization` runs `interation=player_recon_single_view_iteration` = 100 Adam steps unless told otherwise
+    (`PR/player_recon.py:1051,1200`, `S/global_var.py:75`); the bench and most parity tests stop at 50 (north star).  Here the
+    mirror's DEFAULT length against the autograd oracle on five fresh players: raw parameters within 2e-4 after 100 steps (1e-4 is
+    the bound at 50; Adam's sign-sensitive steps let the two fp32 trajectories drift apart with length), vertices within 2e-4 m."""
+    from soccerplayershapepose_amd.player_recon import single_view_optimization
+    from oracle import fit as OF, smpl as OS
+    B = 5
+    R, b, cam = S.pose_params(B, seed=121)
+    R2, b2, _ = S.pose_params(B, seed=122, body_deg=10, global_deg=12)
+    Rp = (R2.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    _, jp = OS.smpl_forward_np(smpl_model_np, Rp, b + b2 / 3)
+    tgt = S.fit_targets_from_joints(jp, cam * np.array([0.93, 1, 1], np.float32), seed=19)
+    Rt, bt, ct = (torch.from_numpy(a) for a in (R, b, cam))
+    rec = single_view_optimization(smpl_gpu, Rt[:, 1:].to(dev), Rt[:, :1].to(dev), bt.to(dev), ct.to(dev), tgt)     # no `interation`: 100
+    o = OF.fit_pose_shape_batch(oracle_smpl, Rt[:, 1:], Rt[:, :1], bt, tgt, ct, iters=100)['last']
+    got = (rec.body_pose, rec.global_orient, rec.betas, rec.cam_wp)
+    d = [(g.cpu() - w).abs().max().item() for g, w in zip(got, o[:4])]
+    assert max(d) < 2e-4, d
+    np.testing.assert_allclose(rec.translation.cpu().numpy(), o[4].numpy(), rtol=2e-4)
+    o50 = OF.fit_pose_shape_batch(oracle_smpl, Rt[:, 1:], Rt[:, :1], bt, tgt, ct, iters=50)['last']
+    assert (o50[0] - o[0]).abs().max().item() > 1e-3          # (the second 50 steps do move the pose: the default length matters)
+    with torch.no_grad():
+        v = oracle_smpl(body_pose=o[0], global_orient=o[1], betas=o[2]).vertices
+    vg = smpl_gpu(body_pose=rec.body_pose, global_orient=rec.global_orient, betas=rec.betas).vertices
+    assert (vg.cpu() - v).abs().max().item() < 2e-4
 
 
 def test_fit_is_deterministic_and_batch_independent(smpl_gpu, dev):
@@ -518,7 +549,6 @@ def test_reference_best_iterate_rule_with_the_rendered_silhouette_metric(smpl_gp
         np.testing.assert_allclose(out.l2e_history[b].cpu().numpy(), rec['l2e'], rtol=2e-3)
         np.testing.assert_allclose(out.silhouette_metric_history[b].cpu().numpy(), sil_o, rtol=5e-3)
         best = OSil.select_best(rec['l2e'], sil_o)
-        assert 0 < best < iters - 1 or len(set(np.argsort(rec['l2e'])[:1]) | {best}) >= 1
         assert int(out.best_iter[b]) == best, (int(out.best_iter[b]), best, rec['l2e'], sil_o)
         body, Gm, be, ca = pre[best]
         np.testing.assert_allclose(out.body_pose[b].cpu().numpy(), np.asarray(body)[0], atol=2e-4)
@@ -682,7 +712,7 @@ def test_broad_view_optimization_against_the_autograd_oracle(smpl_gpu, oracle_sm
     rend = SilhouetteRenderer(smpl_gpu.faces, max_batch=4).to(dev)
     out = broad_view_optimization(smpl_gpu, R[:, 1:], G0, betas, cam0, tgt, interation=12, lr=0.05, select_mode=FIT_SELECT_REFERENCE,
                                   silhouette=sil_t, renderer=rend)
-    for b in (0,):        # (the oracle renders 24 silhouettes per player on the CPU: one player under the two-metric rule, both above)
+    for b in (range(B) if FULL_ORACLE else (0,)):        # (the oracle renders 24 silhouettes per player on the CPU: one player under the two-metric rule unless SPSP_TEST_FULL, both above)
         metric = lambda verts, c, b=b: OSil.silhouette_metric(OSil.render_silhouette(verts.astype(np.float32), smpl_model_np['faces'],
                                                                G.wp_to_translation(torch.from_numpy(c[None])).numpy()[0]), sil_t[b])
         ref = OF.fit_broad_view(oracle_smpl, torch.from_numpy(R[b:b + 1, 1:]), torch.from_numpy(G0[b:b + 1]), torch.from_numpy(betas[b:b + 1]),
@@ -708,7 +738,7 @@ def test_multi_view_fit_against_oracle(smpl_gpu, oracle_smpl, smpl_model_np, dev
     iters, rounds = 6, 2
     # (V = 3, 2, 4 with two players each passed in round 3; two players at V = 3, one at V = 2 and 4 keep the CPU oracle -- 48 V
     # autograd passes per player -- inside a minute on a slow host)
-    for V, seed, nplayers in ((3, 31, 2 if optimise_body_pose else 1), (2, 7, 1), (4, 19, 1)):
+    for V, seed, nplayers in ((3, 31, 2 if (optimise_body_pose or FULL_ORACLE) else 1), (2, 7, 2 if FULL_ORACLE else 1), (4, 19, 2 if FULL_ORACLE else 1)):
         cases = [multiview_case(smpl_model_np, V, seed=seed + 100 * b) for b in range(nplayers)]
         # the single-view results live in npz records (a14): write them, load them, start the multi-view fit from them
         recs = []
@@ -1165,15 +1195,37 @@ def test_ief_called_twice_on_the_same_features_gives_the_same_answer(regressor_s
             assert torch.equal(cam, want[0]) and torch.equal(pose, want[1]) and torch.equal(betas, want[2])
 
 
-def test_predict_3d_mirror(regressor_gpu, smpl_gpu, dev):
+def test_predict_3d_mirror_against_the_oracle_path(regressor_gpu_f16, smpl_gpu, oracle_smpl, regressor_sd_np, dev):
+    """`predict_3D` (`PR/predict/predict_3D.py:128-149`: regressor -> rot6d -> SMPL mesh -> vertices projected to the 512-px
+    image -> the reposed T-pose mesh `smpl(betas=pred_shape)`) by VALUE against the all-fp32 oracle on the same proxies: the
+    hand-made silhouette + joints through the reference's own proxy builder, and three synthetic crops.  Tolerances: the fp16
+    backbone's pre-fit bounds -- cam / pose6d / betas 5e-4, vertices and reposed vertices 2.5e-4 m, projected vertices
+    0.25 px of 512."""
     from soccerplayershapepose_amd.predict.predict_3D import predict_3D, create_proxy_representation
+    from oracle import regressor as OR, geometry as G
     sil = np.zeros((512, 512)); sil[100:420, 180:330] = 1
     j = np.stack([np.linspace(190, 320, 17), np.linspace(110, 410, 17), np.ones(17)], axis=1)
     proxy = create_proxy_representation(sil, j, in_wh=512, out_wh=256)
     assert proxy.shape == (18, 256, 256)
-    out = predict_3D(torch.from_numpy(proxy[None]).float().to(dev), regressor_gpu, smpl_gpu)
-    assert out.pred_vertices.shape == (1, 6890, 3) and out.pred_reposed_vertices.shape == (1, 6890, 3)
-    assert out.pred_vertices2d.shape == (1, 6890, 2) and torch.isfinite(out.pred_vertices).all()
+    x = np.concatenate([proxy[None].astype(np.float32), S.proxy_crops(3, seed=83)[0]])
+    B = x.shape[0]
+    out = predict_3D(torch.from_numpy(x).float().to(dev), regressor_gpu_f16, smpl_gpu)
+    assert out.pred_vertices.shape == (B, 6890, 3) and out.pred_reposed_vertices.shape == (B, 6890, 3)
+    assert out.pred_vertices2d.shape == (B, 6890, 2) and torch.isfinite(out.pred_vertices).all()
+    with torch.no_grad():
+        cam, pose, shape = OR.regressor_forward(regressor_sd_np, x, S.mean_params())
+        R = G.rot6d_to_rotmat(pose).view(B, 24, 3, 3)
+        o = oracle_smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=shape)
+        v2d = G.undo_keypoint_normalisation(G.orthographic_project(o.vertices, cam), 512)
+        eye = torch.eye(3).expand(B, 24, 3, 3)
+        rep = oracle_smpl(body_pose=eye[:, 1:], global_orient=eye[:, :1], betas=shape).vertices
+    dev_of = lambda a, b: (a.cpu() - b).abs().max().item()
+    assert dev_of(out.pred_cam_wp, cam) < 5e-4 and dev_of(out.pred_shape, shape) < 5e-4
+    assert dev_of(out.pred_pose_rotmats, R) < 1e-3
+    assert dev_of(out.pred_vertices, o.vertices) < 2.5e-4, dev_of(out.pred_vertices, o.vertices)
+    assert dev_of(out.pred_joints[:, :24], o.joints[:, :24]) < 2.5e-4
+    assert dev_of(out.pred_vertices2d, v2d) < 0.25, dev_of(out.pred_vertices2d, v2d)
+    assert dev_of(out.pred_reposed_vertices, rep) < 2.5e-4, dev_of(out.pred_reposed_vertices, rep)
 
 
 # ---------------------------------------------------------------- throughput mode (multi-stream slots, HIP graphs)
@@ -1438,11 +1490,13 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
     """Config 4: one match frame = 22 players in one call (ragged w.r.t. every tile size).  Config 5: the 30-frame clip in
     which frame t's fit starts from frame t-1's result (`single_view_optimization` given the previous record as the warm
     start) while the targets move smoothly (2 deg / frame).  Two of the players are followed through the whole
-    clip by the CPU oracle in two ways: TEACHER-FORCED (the oracle fit of a frame starts from the GPU's previous state: 2e-4 on
-    raw parameters -- per-frame errors cannot hide behind each other; frames 1, 10, 20 and 29: all 30 passed in round 3, an
-    oracle fit takes 2.4 s) and FREE-RUNNING (the oracle chains its own results from the same regressor outputs: 2e-4 per frame
-    over the first three frames, and the vertices after ten chained fits within the north-star 1e-3 m -- rounds 3 and 4 chained all
-    30 and passed the same bound; the later frames keep their teacher-forced checks)."""
+    clip by the CPU oracle in two ways: TEACHER-FORCED, ALL 30 frames (the oracle fit of a frame starts from the state the GPU fit of
+    that frame started from -- the regressor's outputs for frame 0, the GPU's previous result after that: 2e-4 on raw parameters, so
+    per-frame errors cannot hide behind each other; the 60 (frame, player) fits are independent, so they run after the GPU clip as
+    ONE `fit_pose_shape_batch` call -- seconds, where 30 separate oracle fits of 2.4 s of framework overhead each made round 4 thin
+    this check to four frames) and FREE-RUNNING (the oracle chains its own results from the same regressor outputs: 2e-4 per frame
+    over the first three frames, and the vertices after ten chained fits -- all 30 with SPSP_TEST_FULL=1 -- within the north-star
+    1e-3 m; rounds 3 and 4 chained all 30 and passed the same bound)."""
     from soccerplayershapepose_amd.player_recon import reconstruct_players, single_view_optimization
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
     from oracle import fit as OF, smpl as OS
@@ -1463,44 +1517,43 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
     res = reconstruct_players(regressor_gpu, smpl_gpu, xt, targets[0], fit='pose_shape', iters=50)
     assert res.vertices.shape == (N, 6890, 3) and torch.isfinite(res.vertices).all()
     body, orient, betas, cam = res.rotmats[:, 1:], res.rotmats[:, :1], res.betas, res.cam
-    start = {i: (R0[i:i + 1, 1:].cpu(), R0[i:i + 1, :1].cpu(), shape0[i:i + 1].cpu(), cam0[i:i + 1].cpu()) for i in follow}
-    free = dict(start)          # the oracle's own chain
-    forced = dict(start)        # what the GPU fit of the coming frame starts from
-    worst_forced = worst_free = vdev = 0.0
-    FREE = 10                   # frames the oracle chains on its own (an oracle fit takes 2.4 s: all 30 were chained in rounds 3 / 4)
+    fl = list(follow)
+    free = (R0[fl, 1:].cpu(), R0[fl, :1].cpu(), shape0[fl].cpu(), cam0[fl].cpu())      # the oracle's own chain (both followed players)
+    started, ended, tgs = [free], [], []        # per frame: what the GPU fit started from / ended at (followed players), its targets
+    worst_free = vdev = 0.0
+    FREE = T if FULL_ORACLE else 10             # frames the oracle chains on its own (each a serial 2.4 s oracle fit)
     for t in range(T):
         if t > 0:
             rec = single_view_optimization(smpl_gpu, body, orient, betas, cam, targets[t], interation=50)
             body, orient, betas, cam = rec.body_pose, rec.global_orient, rec.betas, rec.cam_wp
-        fl = list(follow)
         gpu_now = (body[fl].cpu(), orient[fl].cpu(), betas[fl].cpu(), cam[fl].cpu())
         tg = np.stack([targets[t][i] for i in fl])
-        cat = lambda d, k: torch.cat([d[i][k] for i in fl])
-        if t in (1, 10, 20, 29):                 # (both followed players in one batched oracle fit: oracle/fit.py:fit_pose_shape_batch)
-            o = OF.fit_pose_shape_batch(oracle_smpl, cat(forced, 0), cat(forced, 1), cat(forced, 2), tg, cat(forced, 3), iters=50)['last']
-            d = max((gpu_now[k] - o[k]).abs().max().item() for k in range(4))
-            worst_forced = max(worst_forced, d)
-            assert d < 2e-4, f'frame {t}: {d} from the oracle fit started at the same state'
+        ended.append(gpu_now)
+        tgs.append(tg)
+        if t + 1 < T:
+            started.append(gpu_now)
         if t < FREE:
-            f = OF.fit_pose_shape_batch(oracle_smpl, cat(free, 0), cat(free, 1), cat(free, 2), tg, cat(free, 3), iters=50)['last']
+            f = OF.fit_pose_shape_batch(oracle_smpl, free[0], free[1], free[2], tg, free[3], iters=50)['last']
             d = max((gpu_now[k] - f[k]).abs().max().item() for k in range(4))
             worst_free = max(worst_free, d)
             if t < 3:
                 assert d < 2e-4, f'frame {t}: {d} from the free-running oracle chain'
-        for n, i in enumerate(fl):
-            forced[i] = tuple(g[n:n + 1] for g in gpu_now)
-            if t < FREE:
-                free[i] = tuple(f[k][n:n + 1].detach() for k in range(4))
+            free = tuple(f[k].detach() for k in range(4))
         if t == FREE - 1:       # the vertices after FREE chained fits, GPU chain against oracle chain
             out = smpl_gpu(body_pose=body, global_orient=orient, betas=betas)
-            for i in follow:
-                with torch.no_grad():
-                    v = oracle_smpl(body_pose=free[i][0], global_orient=free[i][1], betas=free[i][2]).vertices[0]
-                vdev = max(vdev, (out.vertices[i].cpu() - v).abs().max().item())
+            with torch.no_grad():
+                v = oracle_smpl(body_pose=free[0], global_orient=free[1], betas=free[2]).vertices
+            vdev = (out.vertices[fl].cpu() - v).abs().max().item()
     out = smpl_gpu(body_pose=body, global_orient=orient, betas=betas)
     assert torch.isfinite(out.vertices).all()
-    print(f'30-frame clip: worst per-frame parameter deviation teacher-forced {worst_forced:.2e}, free-running ({FREE} frames) {worst_free:.2e}; '
-          f'vertices after {FREE} chained fits vs the free-running oracle chain {vdev:.2e} m')
+    # teacher-forced, every frame: 2 T independent fits in one autograd graph
+    o = OF.fit_pose_shape_batch(oracle_smpl, *(torch.cat([st[k] for st in started]) for k in range(3)), np.concatenate(tgs),
+                                torch.cat([st[3] for st in started]), iters=50)['last']
+    per_frame = torch.stack([(torch.cat([e[k] for e in ended]) - o[k]).abs().reshape(T, -1).amax(dim=1) for k in range(4)]).amax(dim=0).numpy()
+    worst_forced = float(per_frame.max())
+    print(f'30-frame clip: worst per-frame parameter deviation teacher-forced (all {T} frames) {worst_forced:.2e}, free-running ({FREE} frames) '
+          f'{worst_free:.2e}; vertices after {FREE} chained fits vs the free-running oracle chain {vdev:.2e} m')
+    assert worst_forced < 2e-4, f'frame {int(np.argmax(per_frame))}: {worst_forced} from the oracle fit started at the same state'
     assert vdev < 1e-3
 
 
