@@ -219,13 +219,17 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_PLAN_STEM_BAND 9        /* conv rows per workgroup of the stem kernel (0: grid-filling default, 16, 32, 64; capped where fewer than a quarter of the CUs would get a workgroup) */
 #define SPSP_DEBUG_PLAN_WRES_CUS 8         /* layer1's persistent workgroups on 1 / value of the CUs (1, 2, 4, 8, 16): more tiles per resident weight set */
 #define SPSP_DEBUG_PLAN_P4 7               /* bit L set: the 3x3 stride-1 convs of layer L+1 on conv_p4.hip (256-pixel tiles, no K split, producer waves); default: bit 1 = layer2 */
+#define SPSP_DEBUG_IEF_BLOCK 12            /* players per block of the fused IEF (the 64 workgroups that hand their hidden vectors to each other): 32, or 16 = two independent halves per 32 players */
 #define SPSP_DEBUG_PLAN_S2RS 6             /* 0: layer2.0's stride-2 pair on the streaming kernel of the other stages, 1 (default): weights stationary in registers */
 int spsp_regressor_debug(spsp_regressor* r, int what, int value);
 /* Test hook of an SMPL handle.  SPSP_DEBUG_FIT_SCHEDULE: which form of the reprojection-fit kernel spsp_fit / spsp_pipeline launch on
- * this handle -- 2 (default) the current schedule, 1 the ten-barrier schedule of rounds 1-3 (tree walks), 0 the level-by-level sweeps
+ * this handle -- 2 (default) the current schedule, 1 the ten-barrier schedule of rounds 1-3 (tree walks, every IEEE division and
+ * square root), 0 the level-by-level sweeps
  * (what a model with a tree other than SMPL's always gets).  Same algorithm; A/B switch of tests and tools, never read from the
  * environment. */
 #define SPSP_DEBUG_FIT_SCHEDULE 1
+/* SPSP_DEBUG_SKIN_PLAYERS: players per workgroup of the SMPL skin kernel, 8 (default) or 16 (the blend basis read half as often; slower). */
+#define SPSP_DEBUG_SKIN_PLAYERS 2
 int spsp_smpl_debug(spsp_smpl* s, int what, int value);
 /* Debug/parity tap: copies the (unpadded) NHWC bf16 output of stage `stage`
  * (1 maxpool, 2..5 layer1..layer4; stage 0 -- conv1+relu -- no longer exists as a map since conv1 and the max-pool are one

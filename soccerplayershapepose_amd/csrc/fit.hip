@@ -149,7 +149,7 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel2(FitParams P, cons
                                                   float* __restrict__ betas, float* __restrict__ cam,
                                                   const float* __restrict__ joints2d, float* __restrict__ loss_hist,
                                                   float* __restrict__ l2e_hist, float* __restrict__ param_hist,
-                                                  const spsp::FitEnds E, unsigned long long* __restrict__ dbg) {
+                                                  const spsp::FitEnds E, unsigned long long* __restrict__ dbg, const spsp::FitSchedule sched) {
     __shared__ FitShared s;
     __shared__ Fit2Shared x;
     __shared__ float sR0[216];
@@ -176,10 +176,16 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel2(FitParams P, cons
     double b1t = 1.0, b2t = 1.0;
     const float w1 = (float)(1.0 - P.beta1), b2f = (float)P.beta2, w2 = (float)(1.0 - P.beta2), epsf = (float)P.eps;
     for (int it = 0; it < P.iters; ++it) {
-        b1t *= P.beta1;
-        b2t *= P.beta2;
-        const float step_size = (float)(P.lr / (1.0 - b1t));
-        const float bc2_sqrt = (float)sqrt(1.0 - b2t);
+        // Adam's bias corrections: from the launch's table (host, double); beyond it, in the loop as before round 5
+        float step_size, inv_bc2;
+        if (it < kFitSchedN) { step_size = sched.step_size[it]; inv_bc2 = sched.inv_bc2[it]; }
+        else {
+            if (it == kFitSchedN) { b1t = sched.b1t_end; b2t = sched.b2t_end; }
+            b1t *= P.beta1;
+            b2t *= P.beta2;
+            step_size = (float)(P.lr / (1.0 - b1t));
+            inv_bc2 = (float)(1.0 / sqrt(1.0 - b2t));
+        }
         float* const ph = param_hist ? param_hist + ((size_t)b * P.iters + it) * kNumPrm : nullptr;
         STAMP(0);
         fit2_p1(s, x, r, lane);                                      __syncthreads();
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel2(FitParams P, cons
         STAMP(8);
         if (wave == 3) { fit2_p11a(s, x, lane); wave_phase_fence(); }
         const float g_rot = fit2_dr(s, r, lane);
-        fit2_step(s, x, r, lane, g_rot, w1, b2f, w2, epsf, step_size, bc2_sqrt, ph);
+        fit2_step(s, x, r, lane, g_rot, w1, b2f, w2, epsf, step_size, 0.f, inv_bc2, ph);
         STAMP(9);
         __syncthreads();
         STAMP(10);
@@ -225,6 +231,7 @@ __global__ __launch_bounds__(spsp::kFitLanes) void fit_kernel2(FitParams P, cons
     if (E.translation && lane < 3)
         E.translation[(size_t)b * 3 + lane] = wp_translation(src[0], src[1], src[2], E.focal, E.resolution, lane);
 }
+
 
 }  // namespace
 
@@ -255,6 +262,11 @@ int spsp_smpl_debug(spsp_smpl* s, int what, int value) {
     if (what == SPSP_DEBUG_FIT_SCHEDULE) {
         SPSP_REQUIRE(value >= 0 && value <= 2, "spsp_smpl_debug: fit schedule %d (0 level sweeps, 1 ten-barrier walks, 2 default)", value);
         s->fit_schedule = value;
+        return SPSP_OK;
+    }
+    if (what == SPSP_DEBUG_SKIN_PLAYERS) {
+        SPSP_REQUIRE(value == 8 || value == 16, "spsp_smpl_debug: %d players per skin workgroup (8 or 16)", value);
+        s->skin_players = value;
         return SPSP_OK;
     }
     spsp::set_error("spsp_smpl_debug: unknown hook %d", what);
@@ -310,9 +322,19 @@ int fit_launch(spsp_ctx* ctx, spsp_smpl* s, const spsp_fit_config* cfg, float* R
                   s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg)
     // (the level sweeps remain for models whose tree is not SMPL's; the older schedules are the A/B switch of tests and tools:
     //  spsp_smpl_debug(s, SPSP_DEBUG_FIT_SCHEDULE, 1) = the ten-barrier schedule of rounds 1-3 with the walks, 0 = with the level sweeps)
-    if (s->walk_ok && s->fit_schedule == 2)
+    if (s->walk_ok && s->fit_schedule == 2) {
+        FitSchedule sched;
+        double b1t = 1.0, b2t = 1.0;
+        for (int t = 0; t < kFitSchedN; ++t) {
+            b1t *= cfg->beta1;
+            b2t *= cfg->beta2;
+            sched.step_size[t] = (float)(cfg->lr / (1.0 - b1t));
+            sched.inv_bc2[t] = (float)(1.0 / std::sqrt(1.0 - b2t));
+        }
+        sched.b1t_end = b1t; sched.b2t_end = b2t;
         launch_kernel(&fit_kernel2, dim3(B), dim3(kFitLanes), 0, as_stream(stream), P, s->walk, s->fitc, s->parents, s->level_joints,
-                      s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg);
+                      s->d_level_start, s->child_start, s->child_list, R, betas, cam, joints2d, loss_hist, l2e_hist, param_hist, ends, dbg, sched);
+    }
     else if (s->walk_ok && s->fit_schedule == 1) SPSP_FIT_LAUNCH(true); else SPSP_FIT_LAUNCH(false);
 #undef SPSP_FIT_LAUNCH
     if (dbg) {

@@ -77,6 +77,26 @@ SPSP_HD void st4(float* p, float a, float b, float c, float d) {
 }
 SPSP_HD float dot4(const F4& a, const F4& b, float acc) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc)))); }
 
+// Round 5: the v2 schedule stops being bit-identical to the older ones ON THE GPU (the parity bar is the oracle: 5e-5 per golden
+// iterate, 1e-4 live).  Its Adam step and the l2e metric take the hardware's 1-ulp square root and reciprocal (v_sqrt_f32,
+// v_rcp_f32) in place of the IEEE sequences (~30 dependent instructions of a lone wave on the critical path of every
+// iteration), and the two bias corrections come from a per-launch table (FitSchedule) instead of ~32 fp64 instructions --
+// a division and a square root in double -- per iteration.  The host twins keep the IEEE forms, so tests/emul still runs the
+// schedules side by side bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__)
+SPSP_HD float fit_sqrt_1ulp(float x) { return __builtin_amdgcn_sqrtf(x); }
+SPSP_HD float fit_rcp_1ulp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+SPSP_HD float fit_sqrt_1ulp(float x) { return sqrtf(x); }
+SPSP_HD float fit_rcp_1ulp(float x) { return 1.0f / x; }
+#endif
+
+// torch.optim.Adam's two bias-correction factors of iterations 1 .. kFitSchedN, computed on the host in double as the kernels'
+// loops do (running products of beta1 / beta2) and passed by value: step_size = lr / (1 - beta1^t), inv_bc2 = 1 / sqrt(1 - beta2^t).
+// Longer fits compute the factors in the loop from iteration kFitSchedN on.
+constexpr int kFitSchedN = 112;
+struct FitSchedule { float step_size[kFitSchedN]; float inv_bc2[kFitSchedN]; double b1t_end, b2t_end; };   // (..._end: beta^kFitSchedN, where the loop takes over)
+
 struct FitParams {           // kernel arguments (plain data)
     int iters;
     double lr, beta1, beta2, eps;
@@ -805,15 +825,22 @@ SPSP_HD void fit2_vp(FitShared& s, int lane) {
 
 // torch.optim.Adam step of the lane's own parameter p from gradient g (fit_p12's statements), published where it is read
 SPSP_HD void fit2_adam(FitShared& s, Fit2Shared& x, FitLane& r, int p, float g, float w1, float b2, float w2, float eps, float step_size,
-                       float bc2_sqrt, float* param_hist_row) {
+                       float bc2_sqrt, float inv_bc2, float* param_hist_row) {
     const float cur = s.prm[p];
     if (param_hist_row) param_hist_row[p] = cur;                  // the iterate this iteration evaluated
     if (s.take_best) s.best[p] = cur;
     if (!r.trainable) return;
     r.m = r.m + w1 * (g - r.m);
     r.v = r.v * b2 + (w2 * g) * g;
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)bc2_sqrt;
+    const float denom = fmaf(fit_sqrt_1ulp(r.v), inv_bc2, eps);  // (a denormal v reads as 0: denom = eps, as sqrt(v) / bc2 + eps rounds to)
+    const float nv = fmaf((-step_size) * r.m, fit_rcp_1ulp(denom), cur);
+#else
+    (void)inv_bc2;
     const float denom = sqrtf(r.v) / bc2_sqrt + eps;
     const float nv = cur + ((-step_size) * r.m) / denom;
+#endif
     s.prm[p] = nv;
     if (p >= kPrmBeta) x.beta4[p - kPrmBeta] = nv;
     else if (p >= kPrmR) fit2_publish_rotation(s, x, p, nv);
@@ -856,8 +883,15 @@ SPSP_HD Fit2P6 fit2_p6a(FitShared& s, int lane, const FitParams& P, float& d_out
     const float px = (u + 1.f) * half;
     const float y = s.tgt_px[joint * 2 + c];
     float n, ns;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // round 5: x * (1 / loss_wh) for every loss_wh (exact for the powers of two the reference uses; else within an ulp of the
+    // division) -- hipcc if-converted the two forms and ran the two IEEE divisions in every iteration
+    (void)lw_pow2;
+    n = (2.0f * px) * lw_inv - 1.0f; ns = (2.0f * y) * lw_inv - 1.0f;
+#else
     if (lw_pow2) { n = (2.0f * px) * lw_inv - 1.0f; ns = (2.0f * y) * lw_inv - 1.0f; }
     else { n = (2.0f * px) / P.loss_wh - 1.0f; ns = (2.0f * y) / P.loss_wh - 1.0f; }
+#endif
     const float d = n - ns;
     const float dp = px - y;
     const float gu = coef * d * dn_du;                       // dL/du
@@ -874,7 +908,7 @@ SPSP_HD void fit2_p6b(FitShared& s, int lane, const Fit2P6& x_link, float d, flo
     if (!(lane & 1)) return;
     float* rp = s.rpart + (lane >> 1) * 5;
     rp[0] = fmaf(d, d, x_link.loss);
-    rp[1] = sqrtf(fmaf(dp, dp, x_link.l2));
+    rp[1] = fit_sqrt_1ulp(fmaf(dp, dp, x_link.l2));
     rp[2] = fmaf(gu, xt, x_link.gs);
 }
 #if defined(__HIPCC__)
@@ -973,7 +1007,7 @@ SPSP_HD void fit2_p11a(FitShared& s, const Fit2Shared& x, int lane) {
 // The Adam step of every parameter, in its owner's lane: rotation entries from the register gradient of fit2_p10, the camera from
 // P7's reductions, the betas (wave 3, behind fit2_p11a and a wave-local hand-off) from the 16 partial sums in fit_p12's order.
 SPSP_HD void fit2_step(FitShared& s, Fit2Shared& x, FitLane& r, int lane, float g_rot, float w1, float b2, float w2, float eps,
-                       float step_size, float bc2_sqrt, float* param_hist_row) {
+                       float step_size, float bc2_sqrt, float inv_bc2, float* param_hist_row) {
     const int p = fit2_owned_param(lane);
     if (p < 0) return;
     float g = g_rot;
@@ -983,7 +1017,8 @@ SPSP_HD void fit2_step(FitShared& s, Fit2Shared& x, FitLane& r, int lane, float 
         const F4 a = ld4(pp), b = ld4(pp + 4), c = ld4(pp + 8), d = ld4(pp + 12);
         g = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
     }
-    fit2_adam(s, x, r, p, g, w1, b2, w2, eps, step_size, bc2_sqrt, param_hist_row);
+    fit2_adam(s, x, r, p, g, w1, b2, w2, eps, step_size, bc2_sqrt, inv_bc2, param_hist_row);
 }
+
 
 }  // namespace spsp

@@ -15,8 +15,10 @@ constexpr int kWH = SPSP_PROXY_WH, kCin = SPSP_PROXY_C, kPad = SPSP_PROXY_PAD;
 constexpr int kWHp = SPSP_PROXY_NATIVE_H, kWWp = SPSP_PROXY_NATIVE_W;   // 262 rows x 264 columns
 constexpr size_t kNativeElems = (size_t)kWHp * kWWp * kCin;
 constexpr int kFeat = 512, kNPar = 157, kHid = 512;
-// per-forward counter block: 128-byte lines 0..31 = tile schedulers of the four conv_wres launches (8 each), 32..39 = IEF barriers
-constexpr int kCounterWords = 40 * 32;
+// per-forward counter block: 128-byte lines 0..31 = tile schedulers of the four conv_wres launches (8 each), 32..47 = IEF barriers
+// (one per block of 16 players: 256 / 16)
+constexpr int kIefCounterLines = 16;
+constexpr int kCounterWords = (32 + kIefCounterLines) * 32;
 
 struct ConvDesc { const char* name; const char* bn; int cout, cin, k, stride; };
 const ConvDesc kConvs[SPSP_NUM_CONVS] = {
@@ -144,12 +146,13 @@ __device__ __forceinline__ bool ief_grid_barrier(unsigned int* counter, unsigned
 
 // 2 x 8 float4 of the two players' k-slices, every load sc1 (L1-bypassing, sees other XCDs' write-through stores); the wait is
 // inside the statement: hipcc considers asm outputs written when the statement ends
+template <int PPB>
 __device__ __forceinline__ void ief_load_sc1(const float* x0, const float* x1, int s, bool blocked, float4 (&xa)[8], float4 (&xb)[8]) {
     const float *pa[8], *pb[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = 4 * (16 * u + s);
-        const int off = blocked ? ((k >> 3) * 32) * 8 + (k & 7) : k;        // blocked: x0 / x1 point at the player's slot of block 0
+        const int off = blocked ? ((k >> 3) * PPB) * 8 + (k & 7) : k;       // blocked: x0 / x1 point at the player's slot of block 0
         pa[u] = x0 + off;
         pb[u] = x1 + off;
     }
@@ -179,9 +182,10 @@ __device__ __forceinline__ float ief_row_sum(float v) {
 // One 8-neuron x 2-player product over K = 512: x rows from global memory (blocked: a handed-off vector, sc1 loads from the
 // blocked layout; else the pooled features of the previous launch, plain rows), the weight slice from LDS.  Returns, in lane s
 // of each row, the dot product for (neuron s & 7, player s >> 3).
+template <int PPB>
 __device__ __forceinline__ float ief_product(const float* wl, const float* x0, const float* x1, int s, bool blocked) {
     float4 xa[8], xb[8];
-    ief_load_sc1(x0, x1, s, blocked, xa, xb);
+    ief_load_sc1<PPB>(x0, x1, s, blocked, xa, xb);
     float mine = 0.f;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -199,11 +203,16 @@ __device__ __forceinline__ float ief_product(const float* wl, const float* x0, c
     return mine;
 }
 
-__global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
+// PPB = players per block (a block = the 64 workgroups that hand their hidden vectors to each other): 32 (rounds 2-4: 256 threads)
+// or, round 5, 16 (128 threads): two INDEPENDENT halves per 32 players, each with its own counter -- a workgroup then pulls 32 KB
+// instead of 64 KB through six cross-XCD hand-offs, and the halves' hand-offs interleave.
+template <int PPB>
+__global__ __launch_bounds__(8 * PPB) void ief_fused_kernel(const IefArgs a) {
     extern __shared__ __align__(16) float ief_w[];           // [4][8][512]: W1f, W13, W2, W3 rows 8g..8g+7
+    constexpr int NT = 8 * PPB;                              // threads: (player pair, k-slice of 16)
     const int t = threadIdx.x, g = blockIdx.x, pb = blockIdx.y;
-    const int s = t & 15, pair = t >> 4;                     // k-slice, player pair of this block of 32
-    const int bA = pb * 32 + 2 * pair, bB = bA + 1;
+    const int s = t & 15, pair = t >> 4;                     // k-slice, player pair of this block
+    const int bA = pb * PPB + 2 * pair, bB = bA + 1;
     const int n = 8 * g + (s & 7);                           // the neuron this lane owns ...
     const int b = (s >> 3) ? bB : bA;                        // ... for this player
     const bool live = b < a.B;
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = 4 * (t + 256 * q);             // float index in the [8][512] slice
+            for (int q = 0; q < 1024 / NT; ++q) {
+                const int e = 4 * (t + NT * q);              // float index in the [8][512] slice
                 const int row = 8 * g + e / 512;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < 3 || row < kNPar) v = *reinterpret_cast<const float4*>(src[m] + (size_t)row * 512 + e % 512);
@@ -226,25 +235,25 @@ __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
     }
     __syncthreads();
 
-    // hidden vectors of this block of 32 players: blocked layout, this thread's element (its player, its neuron) = float
-    // g * 256 + t of the 64 KB block; players beyond B are computed (from the last real one) and stored too, so that every
-    // 128-byte line is written whole by one store instruction
-    float* const h1b = a.h1 + (size_t)pb * 32 * kHid;
-    float* const sb = a.s + (size_t)pb * 32 * kHid;
-    const int mine = g * 256 + t;
+    // hidden vectors of this block of PPB players: blocked layout [neuron block g][player][8], this thread's element (its player,
+    // its neuron) = float g * NT + t of the block; players beyond B are computed (from the last real one) and stored too, so that
+    // every 128-byte line is written whole by one store instruction
+    float* const h1b = a.h1 + (size_t)pb * PPB * kHid;
+    float* const sb = a.s + (size_t)pb * PPB * kHid;
+    const int mine = g * NT + t;
     const int pA = 2 * pair, pB = 2 * pair + 1;                    // the pair's slots in the block
-    const float f1 = ief_product(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s, false);
+    const float f1 = ief_product<PPB>(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s, false);
     __hip_atomic_store(h1b + mine, fmaxf(f1 + a.cvec[n], 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
     float ssum = 0.f;
     const float b2 = a.b2[n];
     for (int it = 0; it < a.iters; ++it) {
         if (it > 0) {
-            const float v = ief_product(ief_w + 4096, sb + pA * 8, sb + pB * 8, s, true);
+            const float v = ief_product<PPB>(ief_w + 4096, sb + pA * 8, sb + pB * 8, s, true);
             __hip_atomic_store(h1b + mine, fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok &= ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
         }
-        const float v = ief_product(ief_w + 2 * 4096, h1b + pA * 8, h1b + pB * 8, s, true);
+        const float v = ief_product<PPB>(ief_w + 2 * 4096, h1b + pA * 8, h1b + pB * 8, s, true);
         ssum += fmaxf(b2 + v, 0.f);
         __hip_atomic_store(sb + mine, ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok &= ief_grid_barrier(counter, kIefG * ++phase, a.spin_limit);
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(256) void ief_fused_kernel(const IefArgs a) {
     // host-visible status word is set, so that the next call on the handle returns SPSP_EHIP (spsp_regressor_status).
     if (!ok && t == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (8 * g < kNPar) {
-        float v = a.p0[n < kNPar ? n : 0] + ief_product(ief_w + 3 * 4096, sb + pA * 8, sb + pB * 8, s, true);
+        float v = a.p0[n < kNPar ? n : 0] + ief_product<PPB>(ief_w + 3 * 4096, sb + pA * 8, sb + pB * 8, s, true);
         if (!ok) v = __builtin_nanf("");
         if (live && n < kNPar) {
             if (n < 3) a.cam[b * 3 + n] = v;
@@ -328,6 +337,7 @@ struct spsp_regressor {
     // workgroup does, with the tile-scheduler words); an IEF call uses them up.  spsp_regressor_ief on a handle whose counters are
     // not fresh (IEF run twice on the same features, IEF before any backbone) zeroes its eight lines itself with a memset node.
     bool ief_counters_fresh = false;
+    int ief_block = 32;                 // players per IEF block (64 workgroups that hand off to each other): 32, or 16 = two independent halves
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
 
@@ -496,9 +506,13 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // ever partly resident; progress is guaranteed while (concurrent forwards) x 64 fits into what the device holds:
         // occupancy x CUs (2 per CU at 64 KB of LDS: 512 on MI355X = 8 concurrent forwards).  Checked here, documented in
         // spsp.h; a hand-off that still starves times out and is reported (spsp_regressor_status).
-        TRY(ensure_dynamic_lds<&ief_fused_kernel>(kIefLds));
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ief_fused_kernel, 256, kIefLds) != hipSuccess) per_cu = 0;
+        TRY(ensure_dynamic_lds<&ief_fused_kernel<32>>(kIefLds));
+        TRY(ensure_dynamic_lds<&ief_fused_kernel<16>>(kIefLds));
+        // (a unit = the 64 workgroups of one block, of 32 or of 16 players: 64 KB of LDS each either way)
+        int per_cu = 0, per_cu16 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ief_fused_kernel<32>, 256, kIefLds) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_fused_kernel<16>, 128, kIefLds) != hipSuccess) per_cu16 = 0;
+        if (per_cu16 < per_cu) per_cu = per_cu16;
         r->ief_capacity = per_cu * ctx->num_cus;
         if (w->ief_iters > 0 && r->ief_capacity < kIefG * SPSP_REGRESSOR_MAX_CONCURRENT) {
             const int cap = r->ief_capacity;
@@ -645,7 +659,8 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
     SPSP_REQUIRE(B >= 0 && B <= r->max_batch, "spsp_regressor_ief: B=%d exceeds max_batch=%d", B, r->max_batch);
     hipStream_t st = as_stream(stream);
     if (r->ief_iters > 0) {
-        const int npb = (B + 31) / 32;
+        const int ppb = r->ief_block;               // players per block of 64 workgroups: 16 (two independent halves per 32 players) or 32
+        const int npb = (B + ppb - 1) / ppb;
         IefArgs ia;
         ia.feats = r->feats; ia.w1f = r->w1f; ia.w13 = r->w13; ia.w2 = r->w2; ia.w3 = r->w3;
         ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
@@ -653,7 +668,7 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
         ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed by the backbone call)
         // ... or here, when no backbone call has run since the last IEF on this handle: with used-up counters every hand-off
         // of the launch would pass at once and the kernel would read hidden vectors that are not written yet
-        if (!r->ief_counters_fresh) SPSP_HIP_CHECK(hipMemsetAsync(ia.counters, 0, 8 * 32 * sizeof(unsigned int), st));
+        if (!r->ief_counters_fresh) SPSP_HIP_CHECK(hipMemsetAsync(ia.counters, 0, kIefCounterLines * 32 * sizeof(unsigned int), st));
         r->ief_counters_fresh = false;
         ia.B = B; ia.iters = r->ief_iters;
         ia.err = r->err_dev;
@@ -664,9 +679,11 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
             ief_wgs = kIefG - 1;
             ia.spin_limit = 1u << 9;
         }
-        SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel>(kIefLds));
+        SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel<32>>(kIefLds));
+        SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel<16>>(kIefLds));
         ProfScope ps(ctx, kKIefFc, st, true);
-        launch_kernel(&ief_fused_kernel, dim3(ief_wgs, npb), dim3(256), kIefLds, st, ia);
+        if (ppb == 16) launch_kernel(&ief_fused_kernel<16>, dim3(ief_wgs, npb), dim3(128), kIefLds, st, ia);
+        else launch_kernel(&ief_fused_kernel<32>, dim3(ief_wgs, npb), dim3(256), kIefLds, st, ia);
     } else {
         ProfScope ps(ctx, kKIefMisc, st);
         ief_init_only_kernel<<<(B * kNPar + 255) / 256, 256, 0, st>>>(r->init_params, B, cam, pose6d, betas);
@@ -712,6 +729,10 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
     SPSP_REQUIRE(r, "spsp_regressor_debug: NULL handle");
     switch (what) {
         case SPSP_DEBUG_IEF_STALL: r->debug_ief_stall = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_IEF_BLOCK:
+            SPSP_REQUIRE(value == 16 || value == 32, "spsp_regressor_debug: IEF blocks of %d players (16 or 32)", value);
+            r->ief_block = value;
+            return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)

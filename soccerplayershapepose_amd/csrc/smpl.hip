@@ -27,13 +27,15 @@ constexpr int kChainWaves = 4;        // + four waves that turn (R, betas) of th
                                       // PER PLAYER (12 waves, 62 KB of LDS: two workgroups per CU) is as fast alone and cost the four-slot
                                       // pipeline 1 %: a workgroup that size finds room beside the other slots' convolutions less often
 constexpr int kSkinBlock = kSkinThreads + 64 * kChainWaves;
-constexpr int kPB = 8;   // players per skin workgroup (16 measured slower in round 3: 27.7 vs 19.0 us -- 236 VGPRs and 82 KB of LDS leave one workgroup of four waves per CU)
-constexpr int kChainPlayers = kPB / kChainWaves;
-static_assert(kPB % kChainWaves == 0, "players split evenly over the chain waves");
+// players per skin workgroup: 8.  16 (the blend basis read twice instead of four times per 32 players: `spsp_smpl_debug(
+// SPSP_DEBUG_SKIN_PLAYERS, 16)`) measured slower in round 3 (27.7 vs 19.0 us: 236 VGPRs and 82 KB of LDS leave one workgroup of four
+// waves per CU) and again in round 5 with the chain waves in the kernel (bytes and time)
+constexpr int kPBDefault = 8;
 
 // Per chain wave: its players' rotation matrices and betas (fetched before the workgroup's first barrier) and one player's joints.
+template <int CP>
 struct ChainLds {
-    float R[kChainPlayers][216], beta[kChainPlayers][16], J[72];
+    float R[CP][216], beta[CP][16], J[72];
 };
 
 // One wavefront, one player: J = Jbar + JS . betas, the level-parallel kinematic chain, A_k = [W_k.R | W_k.t - W_k.R J_k]
@@ -66,6 +68,7 @@ __device__ __forceinline__ void chain_one_player(const float* Rm, const float* b
 // partial sums meet in LDS, then wave w skins players (kPB / 4) w .. + kPB / 4 - 1.
 // Waves 4..11 (round 4): the kinematic chain of one of the workgroup's players each (chain_one_player), into sA -- and, from the
 // workgroups of the first vertex tile, into the handle's A workspace (the VJP reads it) and joints 0..23.
+template <int kPB>
 __global__ __launch_bounds__(kSkinBlock) void smpl_skin_kernel(const float* __restrict__ basis,
                                                                const float* __restrict__ v_template,
                                                                const float* __restrict__ wT,
@@ -75,10 +78,13 @@ __global__ __launch_bounds__(kSkinBlock) void smpl_skin_kernel(const float* __re
                                                                const int* __restrict__ level_start, int num_levels,
                                                                float* __restrict__ A_ws, float* __restrict__ joints_out, int B,
                                                                float* __restrict__ verts, float* __restrict__ vposed) {
+    constexpr int kChainPlayers = kPB / kChainWaves;
+    static_assert(kPB % kChainWaves == 0, "players split evenly over the chain waves");
+    typedef ChainLds<kChainPlayers> ChainLdsT;
     __shared__ float sCoef[kPB][kNCoef + 3];
     __shared__ __attribute__((aligned(16))) float sA[kPB][288];
     __shared__ float sPart[4][kPB * 3][64];                // [k-slice][player*3 + c][lane]
-    __shared__ ChainLds sChain[kChainWaves];
+    __shared__ ChainLdsT sChain[kChainWaves];
     __shared__ TreeLds sTree;
     __shared__ float sJc[792];
     const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kSkinBlock) void smpl_skin_kernel(const float* __re
     const int b0 = grp * kPB;
     const int nb = min(kPB, B - b0);
     if (ks >= 4) {
-        ChainLds& c = sChain[ks - 4];
+        ChainLdsT& c = sChain[ks - 4];
         if (ks == 4) load_tree(sTree, parents, level_joints, level_start, num_levels, lane);
         for (int i = threadIdx.x - kSkinThreads; i < 792; i += 64 * kChainWaves) sJc[i] = jconst[i];
 #pragma unroll
@@ -294,10 +300,15 @@ int smpl_forward_impl(spsp_ctx* ctx, spsp_smpl* s, const float* R, const float* 
     if (B == 0 || (!verts && !joints)) return SPSP_OK;
     hipStream_t st = as_stream(stream);
     float* v = verts ? verts : s->ws_verts;
-    dim3 grid((kV + 63) / 64, (B + kPB - 1) / kPB);
+    const int pb = s->skin_players == 16 ? 16 : kPBDefault;
+    dim3 grid((kV + 63) / 64, (B + pb - 1) / pb);
     { ProfScope ps(ctx, kKSmplSkin, st, true);
-      launch_kernel(&smpl_skin_kernel, grid, dim3(kSkinBlock), 0, st, s->basis, s->v_template, s->wT, R, betas, s->jconst, s->parents,
-                    s->level_joints, s->d_level_start, s->num_levels, s->ws_A, joints, B, v, vposed); }
+      if (pb == 16)
+          launch_kernel(&smpl_skin_kernel<16>, grid, dim3(kSkinBlock), 0, st, s->basis, s->v_template, s->wT, R, betas, s->jconst, s->parents,
+                        s->level_joints, s->d_level_start, s->num_levels, s->ws_A, joints, B, v, vposed);
+      else
+          launch_kernel(&smpl_skin_kernel<kPBDefault>, grid, dim3(kSkinBlock), 0, st, s->basis, s->v_template, s->wT, R, betas, s->jconst, s->parents,
+                        s->level_joints, s->d_level_start, s->num_levels, s->ws_A, joints, B, v, vposed); }
     SPSP_HIP_CHECK(hipGetLastError());
     if (joints) {
         ProfScope ps(ctx, kKSmplJoints, st, true);

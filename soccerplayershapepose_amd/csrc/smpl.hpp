@@ -23,6 +23,7 @@ struct spsp_smpl {
     uint32_t* walk;      // [64 * 4 + 25] programs of the fit's tree walks (SmplHostImage::walk)
     bool walk_ok;
     int walk_nb;
+    int skin_players = 8;   // players per workgroup of the skin kernel (8; 16: experiment, spsp_smpl_debug)
     int fit_schedule = 2;   // 2: fit_kernel2 (default) | 1: the ten-barrier schedule with the walks | 0: level sweeps (spsp_smpl_debug)
     int* pick_ids;       // [21]
     int* csr_ptr;        // [46] extra-joint regressors (9 + 19 + 17 rows) in CSR

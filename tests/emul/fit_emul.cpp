@@ -114,7 +114,7 @@ extern "C" int fit_emulate(const spsp_smpl_arrays* model, int iters, double lr,
                 float g_rot[kFitLanes];
                 for (int lane = 192; lane < 256; ++lane) fit2_p11a(s2, x2, lane);                               // wave 3, in front of its gradients and steps
                 ALL_LANES(g_rot[lane] = fit2_dr(s2, r2[lane], lane));
-                ALL_LANES(fit2_step(s2, x2, r2[lane], lane, g_rot[lane], w1, b2f, w2, epsf, step_size, bc2_sqrt, nullptr));
+                ALL_LANES(fit2_step(s2, x2, r2[lane], lane, g_rot[lane], w1, b2f, w2, epsf, step_size, bc2_sqrt, 1.0f / bc2_sqrt, nullptr));
                 if (std::memcmp(s.prm, s2.prm, sizeof(float) * kNumPrm) != 0) return -4;
                 if (std::memcmp(s.best, s2.best, sizeof(float) * kNumPrm) != 0) return -5;
                 if (lh && std::memcmp(&lh[it], &lh2[it], sizeof(float)) != 0) return -6;

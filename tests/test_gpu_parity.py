@@ -257,7 +257,7 @@ def test_fit_variant_b_at_the_reference_default_of_100_iterations(smpl_gpu, orac
     got = (rec.body_pose, rec.global_orient, rec.betas, rec.cam_wp)
     d = [(g.cpu() - w).abs().max().item() for g, w in zip(got, o[:4])]
     assert max(d) < 2e-4, d
-    np.testing.assert_allclose(rec.translation.cpu().numpy(), o[4].numpy(), rtol=2e-4)
+    np.testing.assert_allclose(rec.translation.cpu().numpy(), o[4].numpy(), rtol=2e-4, atol=1e-5)
     o50 = OF.fit_pose_shape_batch(oracle_smpl, Rt[:, 1:], Rt[:, :1], bt, tgt, ct, iters=50)['last']
     assert (o50[0] - o[0]).abs().max().item() > 1e-3          # (the second 50 steps do move the pose: the default length matters)
     with torch.no_grad():
@@ -445,11 +445,13 @@ def test_fit_tree_walks_are_bit_identical_to_the_level_sweeps(smpl_gpu, dev):
     assert not torch.equal(runs[1][0], torch.from_numpy(R).to(dev))         # (the fit did move the pose)
 
 
-def test_fit_schedule_v2_is_bit_identical_to_the_ten_barrier_schedule(smpl_gpu, dev):
-    """csrc/fit.hip fit_kernel2 (the default since round 4: eight barriers per iteration, Adam steps in the lanes that compute the
-    gradients, waves 1 and 3 working beside wave 0's tree walks -- csrc/fit_core.hpp "round 4") against the schedule of rounds 1-3
-    (`spsp_smpl_debug(SPSP_DEBUG_FIT_SCHEDULE, 1)`).  The same operations produce every value in the same order: every iterate of
-    both fit variants and both select modes, the loss / l2e histories and the results, 9 players over 50 iterations, bit for bit."""
+def test_fit_schedule_v2_follows_the_ieee_ten_barrier_schedule(smpl_gpu, dev):
+    """csrc/fit.hip fit_kernel2 (the default: eight barriers per iteration, Adam steps in the lanes that compute the gradients, waves
+    1 and 3 working beside wave 0's tree walks; since round 5 with the hardware's 1-ulp square root / reciprocal in the Adam step
+    and the l2e metric and table-driven bias corrections -- csrc/fit_core.hpp) against the schedule of rounds 1-3, which keeps
+    every IEEE division and square root (`spsp_smpl_debug(SPSP_DEBUG_FIT_SCHEDULE, 1)`).  Bit-identical through round 4 (and
+    still, on the host: tests/emul); on the GPU now held to the oracle's own bar: every iterate of both fit variants and both select
+    modes within 5e-5 on the raw parameters, loss / l2e histories within 1e-4 relative, 9 players over 50 iterations."""
     from soccerplayershapepose_amd.player_recon import fit_players
     B = 9
     R, b, cam = S.pose_params(B, seed=91, body_deg=25, global_deg=40)
@@ -467,12 +469,19 @@ def test_fit_schedule_v2_is_bit_identical_to_the_ten_barrier_schedule(smpl_gpu, 
                     runs[(sched, variant, select)] = [Rg.clone(), bg.clone(), cg.clone()] + [h.clone() for h in hist]
     finally:
         smpl_gpu.debug(_abi.DEBUG_FIT_SCHEDULE, 2)
+    worst = 0.0
     for variant in (0, 1):
         for select in (_abi.FIT_SELECT_LAST, _abi.FIT_SELECT_BEST_L2E):
             new, old = runs[('2', variant, select)], runs[('1', variant, select)]
             assert len(new) == len(old) == 6
-            for x, y in zip(new, old):
-                assert torch.isfinite(x).all() and torch.equal(x, y)
+            for i, (x, y) in enumerate(zip(new, old)):
+                assert torch.isfinite(x).all()
+                if i in (3, 4):          # loss, l2e histories
+                    assert ((x - y).abs() <= 1e-4 * y.abs() + 1e-9).all()
+                else:                    # R, betas, cam, and the trajectory of all 229 parameters
+                    worst = max(worst, (x - y).abs().max().item())
+    print(f'fit v2 (1-ulp sqrt / rcp) vs the IEEE schedule: worst parameter deviation over all iterates {worst:.2e}')
+    assert worst < 5e-5
     assert not torch.equal(runs[('2', 1, _abi.FIT_SELECT_LAST)][0], torch.from_numpy(R).to(dev))
 
 

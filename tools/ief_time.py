@@ -1,0 +1,43 @@
+"""The fused IEF alone (csrc/regressor.hip, ief_fused_kernel): duration between the kernel's own events at B = 32 / 22 / 64 with
+blocks of 32 players (rounds 2-4: 64 workgroups of 256 threads hand their hidden vectors to each other) and of 16 (round 5: two
+independent halves per 32 players, 128 threads each), and whether the outputs are the same bits.
+usage: python tools/ief_time.py [reps]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from soccerplayershapepose_amd import _abi, synthetic as S  # noqa: E402
+from soccerplayershapepose_amd import runtime as rt  # noqa: E402
+from soccerplayershapepose_amd.models.regressor import SingleInputRegressor  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device('cuda', 0)
+r = rt.get(dev)
+nk = r.lib.spsp_profile_num_kernels()
+names = [r.lib.spsp_profile_kernel_name(i).decode() for i in range(nk)]
+sd = S.regressor_state_dict(seed=0)
+for B in (32, 22, 64):
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(sd).to(dev)
+    x, _ = S.proxy_crops(B, seed=3)
+    native = reg.pack(torch.from_numpy(x).to(dev))
+    outs = {}
+    for blk in (32, 16, 32, 16):
+        r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_IEF_BLOCK, blk), 'debug')
+        out = [t.clone() for t in reg(native)]
+        torch.cuda.synchronize()
+        reg.check_status()
+        ms, cnt = (C.c_double * nk)(), (C.c_int * nk)()
+        r.check(r.lib.spsp_profile_select(r.ctx, -1), 'select')
+        r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'enable')
+        for _ in range(reps):
+            reg(native)
+            torch.cuda.synchronize()
+        r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'enable')
+        r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'read')
+        i = names.index('ief_fused_kernel')
+        same = all(torch.equal(a, b) for a, b in zip(out, outs.setdefault(32, out)))
+        print(f'B={B}, IEF blocks of {blk} players: {1e3 * ms[i] / cnt[i]:.2f} us; outputs equal to the 32-player blocks\': {same}', flush=True)

@@ -1,6 +1,7 @@
 """SMPL forward alone: per-kernel durations (the library's profiling scopes: each kernel's own begin / end timestamps) at
-B = 32 / 22 / 8 / 1, and the largest vertex / joint deviation from the float64 oracle twin.
-usage: python tools/smpl_time.py [reps]"""
+B = 32 / 22 / 8 / 1, and the largest vertex / joint deviation from the float64 oracle twin -- with 8 (default) and 16 players per
+skin workgroup (`spsp_smpl_debug(SPSP_DEBUG_SKIN_PLAYERS)`: the blend basis read four times / twice per 32 players).
+usage: python tools/smpl_time.py [reps [batch ...]]"""
 import ctypes as C
 import os
 import sys
@@ -10,7 +11,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from soccerplayershapepose_amd import synthetic as S  # noqa: E402
+from soccerplayershapepose_amd import _abi, synthetic as S  # noqa: E402
 from soccerplayershapepose_amd import runtime as rt  # noqa: E402
 from soccerplayershapepose_amd.models.smpl_official import SMPL  # noqa: E402
 from oracle import smpl as OS  # noqa: E402
@@ -21,8 +22,9 @@ model = S.smpl_model(seed=0)
 r = rt.get(dev)
 nk = r.lib.spsp_profile_num_kernels()
 names = [r.lib.spsp_profile_kernel_name(i).decode() for i in range(nk)]
-for B in [int(v) for v in sys.argv[2:]] or (32, 22, 8, 1):
+for B, PB in [(b_, pb_) for b_ in ([int(v) for v in sys.argv[2:]] or (32, 22, 8, 1)) for pb_ in (8, 16)]:
     smpl = SMPL(model, max_batch=B).to(dev)
+    smpl.debug(_abi.DEBUG_SKIN_PLAYERS, PB)
     R, b, cam = S.pose_params(B, seed=5 + B, body_deg=30, global_deg=60)
     Rt, bt = torch.from_numpy(R).to(dev), torch.from_numpy(b).to(dev)
     out = smpl(body_pose=Rt[:, 1:], global_orient=Rt[:, :1], betas=bt)
@@ -39,4 +41,4 @@ for B in [int(v) for v in sys.argv[2:]] or (32, 22, 8, 1):
     r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'enable')
     r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'read')
     k = ', '.join(f'{names[i]} {1e3 * ms[i] / cnt[i]:.2f} us' for i in range(nk) if cnt[i])
-    print(f'B={B}: {k}; max |vertex - float64 oracle| {ev:.2e} m, joints {ej:.2e} m', flush=True)
+    print(f'B={B}, {PB} players per skin workgroup: {k}; max |vertex - float64 oracle| {ev:.2e} m, joints {ej:.2e} m', flush=True)
