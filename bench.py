@@ -67,6 +67,11 @@ def parse(argv=None):
                     help='run the N>1 code path (RCCL communicators, per-step all-gather, barriers) even with one rank')
     ap.add_argument('--plan-hooks', default='', help=argparse.SUPPRESS)         # experiment: 'what=value,...' (SPSP_DEBUG_PLAN_*) on every slot's regressor
     ap.add_argument('--probe', action='store_true', help=argparse.SUPPRESS)       # diagnostic: re-time the pipeline after the timed region (stderr)
+    ap.add_argument('--profile-pass', default='', choices=['', 'latency', 'throughput'],
+                    help='run ONLY the untimed per-kernel pass of this regressor plan (one batch in flight, a synchronize after every '
+                         'step, no event pairs) and exit without a JSON line: the command tools/gpu_profile.sh puts under rocprofv3 '
+                         '--kernel-trace --stats, so that the tracked trace (profiles/kernel_stats_isolated_<plan>_plan.csv) and '
+                         'roofline.avg_us measure the same launches')
     ap.add_argument('--inputs', type=int, default=0,
                     help='distinct resident input batches rotated through the steps (0 = one per pipeline slot, at least 4): every step '
                          'reads another 80 MB buffer, so the input is streamed from HBM and not re-read from the Infinity Cache')
@@ -119,15 +124,16 @@ def launch_ranks(args, argv):
     raise SystemExit(0)
 
 
-ROCPROF_ISOLATED = os.path.join('profiles', 'kernel_stats_regressor_only.csv')
+def rocprof_isolated_path(plan):
+    return os.path.join('profiles', f'kernel_stats_isolated_{plan}_plan.csv')
 
 
-def rocprof_average_us(table_name):
+def rocprof_average_us(table_name, plan):
     """Average duration of the library kernel `table_name` (e.g. 'conv3x3_patch_kernel<false>') in the tracked rocprofv3
-    kernel trace of `tools/regressor_only.py 32 4 f16` (one batch in flight; profiles/README.md), or None.  The trace names
-    carry every template argument; the table name's arguments are a prefix of them."""
+    kernel trace of `bench.py --profile-pass <plan>` (this file's own per-kernel pass, one batch in flight; profiles/README.md), or
+    None.  The trace names carry every template argument; the table name's arguments are a prefix of them."""
     import csv
-    path = os.path.join(ROOT, ROCPROF_ISOLATED)
+    path = os.path.join(ROOT, rocprof_isolated_path(plan))
     if not os.path.exists(path):
         return None
     base, _, targs = table_name.partition('<')
@@ -393,6 +399,9 @@ def main():
         if use_dist:
             dist.barrier()
 
+    if args.profile_pass:                             # (the trace should hold launches of the one plan only)
+        for sl in pipe.slots:
+            sl.regressor.set_plan(args.profile_pass)
     for _ in range(max(1, len(pipe.slots))):          # first use of every slot (one-time kernel attribute set-up); the --warmup steps
         step()                                        # proper run right in front of the timed region, inside timed()
     torch.cuda.synchronize()
@@ -435,6 +444,14 @@ def main():
         r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'spsp_profile_enable')
         return read_profile(iso_steps)
     pipe_plan = 'throughput' if len(pipe.slots) >= 2 else 'latency'      # (what PlayerPipeline selected for its slots)
+    if args.profile_pass:
+        # the same launches, without event pairs, for rocprofv3's kernel trace (tools/gpu_profile.sh)
+        reg.set_plan(args.profile_pass)
+        for _ in range(4 * iso_steps):
+            pipe._next = 0
+            step()
+            torch.cuda.synchronize()
+        return          # (a normal exit: the profiler writes its trace from an exit handler)
     kernels_iso_tp = isolated_pass('throughput')
     kernels_iso = isolated_pass('latency')
     reg.set_plan(pipe_plan)
@@ -446,10 +463,12 @@ def main():
         fl = r.lib.spsp_profile_kernel_flop_per_crop(v['id'])
         if fl > 0:
             cands[k] = fl * B
-    dom = max(cands, key=lambda k: kernels_iso[k]['us_per_step'])
     cands_tp = {k: r.lib.spsp_profile_kernel_flop_per_crop(v['id']) * B for k, v in kernels_iso_tp.items()
                 if r.lib.spsp_profile_kernel_flop_per_crop(v['id']) > 0 and v['avg_workgroups'] > 0}
     num_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    # ... IN THE PLAN THE TIMED REGION RUNS (round 5; rounds 1-4 took it from the latency plan whatever was timed)
+    iso_sel, cands_sel = (kernels_iso_tp, cands_tp) if pipe_plan == 'throughput' else (kernels_iso, cands)
+    dom = max(cands_sel, key=lambda k: iso_sel[k]['us_per_step'])
 
     # ---- timed region: EXACTLY --steps steps, barrier + synchronize on both sides.  Only the dominant kernel keeps
     # its event pair here: a pair is a barrier on its in-order stream, and bracketing all ~60 launches of a step costs
@@ -485,7 +504,7 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return el.item(), out_
 
-    elapsed, out = timed(step, pipe, kernels_iso[dom]['id'])
+    elapsed, out = timed(step, pipe, iso_sel[dom]['id'])
     if args.probe and args.graphs:
         for label, fn in (('step()', step), ('submit(natives[i % 4], one target set)', None)):
             rates = []
@@ -516,7 +535,7 @@ def main():
         for _ in range(len(pipe.slots)):
             step()
         torch.cuda.synchronize()
-        r.check(r.lib.spsp_profile_select(r.ctx, kernels_iso[dom]['id']), 'spsp_profile_select')
+        r.check(r.lib.spsp_profile_select(r.ctx, iso_sel[dom]['id']), 'spsp_profile_select')
         r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'spsp_profile_enable')
         for _ in range(nprobe):
             step()
@@ -626,8 +645,9 @@ def main():
         del pipe3
 
     if rank == 0:
-        achieved = cands[dom] / (kernels[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels else None
-        achieved_iso = cands[dom] / (kernels_iso[dom]['avg_us'] * 1e-6) / 1e12
+        achieved = cands_sel[dom] / (kernels[dom]['avg_us'] * 1e-6) / 1e12 if dom in kernels else None
+        achieved_iso = cands_sel[dom] / (iso_sel[dom]['avg_us'] * 1e-6) / 1e12
+        cu_share = min(1.0, iso_sel[dom]['avg_workgroups'] / num_cus) if iso_sel[dom]['avg_workgroups'] > 0 else 1.0
         conv_us = sum(v['us_per_step'] for k, v in kernels_iso.items() if k.startswith('conv'))
         pmc_path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         traffic = None
@@ -647,24 +667,28 @@ def main():
                        'regressor_plan': reg.plan + (' + hooks ' + args.plan_hooks if args.plan_hooks else ''),
                        'proxy_built_on_gpu': bool(args.from_detections),
                        'exchange': (exchange.describe() if exchange else None)},
-            # achieved = algorithmic FLOPs of one launch / its average duration between HIP events on its stream with ONE
-            # batch in flight (agrees with the rocprofv3 average).  In the pipelined timed region the same kernel's
-            # event pair also spans the time its workgroups share CUs with other batches' kernels; that figure is
-            # kept as *_timed_region.
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'plan': 'latency', 'achieved': achieved_iso, 'peak': MFMA_PEAK_TFLOPS,
+            # The dominant kernel = the MFMA kernel with the most time per step IN THE PLAN THE TIMED REGION RAN (`plan`); achieved =
+            # algorithmic FLOPs of one launch / its average duration (the kernel's own begin / end timestamps, ONE batch in flight, that
+            # plan's grid) -- against the WHOLE chip's peak, so a narrow launch of plan "throughput" reads low by design: `workgroups`
+            # and `frac_of_cus_used` price it against the CUs it occupies; `end_to_end_backbone_frac` is what the timed region as a
+            # whole achieves.  In the pipelined timed region the same kernel's event pair also spans the time its workgroups share CUs
+            # with other batches' kernels: *_timed_region.  `latency_plan`: the chip-filling launches of the same kernels.
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'plan': pipe_plan, 'achieved': achieved_iso, 'peak': MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved_iso / MFMA_PEAK_TFLOPS,
+                         'workgroups': iso_sel[dom]['avg_workgroups'], 'frac_of_cus_used': achieved_iso / (MFMA_PEAK_TFLOPS * cu_share),
                          'traffic': traffic,
-                         'avg_us': kernels_iso[dom]['avg_us'],
-                         'flop_per_launch': cands[dom],
+                         'avg_us': iso_sel[dom]['avg_us'],
+                         'flop_per_launch': cands_sel[dom],
                          # (with HIP graphs: from the eager continuation of the timed pipeline, see above)
                          'avg_us_timed_region': kernels.get(dom, {}).get('avg_us'),
                          'achieved_timed_region': achieved,
                          'all_convs_tflops': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12) if conv_us else None,
                          'all_convs_frac': (FLOP_BACKBONE * B / (conv_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS) if conv_us else None,
                          # every kernel of the table that does the same work in each launch: isolated duration -> fraction of the peak
-                         'mfma_kernels': {k: {'launches_per_step': kernels_iso[k]['launches_per_step'], 'avg_us': round(kernels_iso[k]['avg_us'], 2),
-                                              'frac': round(f / (kernels_iso[k]['avg_us'] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
-                                          for k, f in cands.items() if k in kernels_iso},
+                         'latency_plan': {'what': 'the same kernels launched chip-filling (a handle\'s default plan; one batch in flight)',
+                                          'mfma_kernels': {k: {'launches_per_step': kernels_iso[k]['launches_per_step'], 'avg_us': round(kernels_iso[k]['avg_us'], 2),
+                                                               'frac': round(f / (kernels_iso[k]['avg_us'] * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                                                           for k, f in cands.items() if k in kernels_iso}},
                          'end_to_end_backbone_tflops': FLOP_BACKBONE * world * B * args.steps / elapsed / 1e12,
                          'end_to_end_backbone_frac': FLOP_BACKBONE * B * args.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS},
             'latency': {'workload': f'one {FRAME_PLAYERS}-player match frame (BASELINE configs[3]) through the whole path, nothing else in '
@@ -684,11 +708,11 @@ def main():
         }
         # cross-check against the TRACKED rocprofv3 kernel trace of the isolated command (same build): the live figure must be
         # reproducible from a file under profiles/
-        rp = rocprof_average_us(dom) if args.precision == 'f16' and B == BATCH_PER_GPU else None
+        rp = rocprof_average_us(dom, pipe_plan) if args.precision == 'f16' and B == BATCH_PER_GPU else None
         if rp is not None:
-            line['roofline']['rocprof'] = {'source': ROCPROF_ISOLATED + ' (rocprofv3 --kernel-trace --stats -- python3 tools/regressor_only.py 32 4 f16)',
-                                           'avg_us': rp, 'frac': cands[dom] / (rp * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
-                                           'live_over_rocprof': kernels_iso[dom]['avg_us'] / rp}
+            line['roofline']['rocprof'] = {'source': rocprof_isolated_path(pipe_plan) + f' (rocprofv3 --kernel-trace --stats -- python3 bench.py --profile-pass {pipe_plan})',
+                                           'avg_us': rp, 'frac': cands_sel[dom] / (rp * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                                           'live_over_rocprof': iso_sel[dom]['avg_us'] / rp}
         if alt is not None:
             line['alt_precision'] = {'dtype': alt['dtype'], 'value': alt['value'], 'unit': 'players/s', 'ms_per_step': alt['ms_per_step']}
         if grouped is not None:

@@ -103,6 +103,7 @@ enum KernelId {
     kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate,
     kKConvS2,          // conv3x3s2_kernel (the three 3x3 / 2 convs + their fused 1x1 / 2 downsamples, parity-plane patch)
     kKConvP4,          // conv3x3_p4_kernel (3x3 / 1 of layer2 and, plan "throughput", layer3: 256-pixel tiles, no K split, producer waves)
+    kKConvFb,          // conv_basic_block_kernel (layer1: a whole BasicBlock per launch, weights in registers, intermediate tile in LDS)
     kKNumKernels
 };
 struct ProfRec { int id; hipEvent_t start, stop; hipStream_t stream; unsigned workgroups; };

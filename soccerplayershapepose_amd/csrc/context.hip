@@ -48,11 +48,12 @@ static const int kTP = 1 << SPSP_PLAN_THROUGHPUT, kLT = 1 << SPSP_PLAN_LATENCY, 
 static const double kFlopConv1 = 2.0 * 924844032.0, kFlop3x3 = 2.0 * 150994944.0;
 static const double kFlopS2 = 2.0 * (75497472.0 + 8388608.0);     // a 3x3 / 2 conv + its 1x1 / 2 downsample
 static const KernelRow kKernels[spsp::kKNumKernels] = {
-    {"conv1_pool_kernel", kFlopConv1, kBoth}, {"conv3x3_wres_kernel", kFlop3x3, kBoth},
+    {"conv1_pool_kernel", kFlopConv1, kBoth}, {"conv3x3_wres_kernel", kFlop3x3, 0},
     {"conv3x3_patch_kernel<false>", kFlop3x3, kLT}, {"conv3x3_patch_kernel<true>", kFlop3x3, kBoth}, {"conv_ring_kernel", 0, 0},
     {"ief_fused_kernel", 0, kBoth}, {"ief_init_only_kernel", 0, 0}, {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0},
     {"rot6d_kernel", 0, 0}, {"fit_kernel2", 0, kBoth}, {"smpl_chain_kernel", 0, 0}, {"smpl_skin_kernel", 0, kBoth},
-    {"smpl_extra_joints_kernel", 0, kBoth}, {"relate_project_kernel+relate_attend_kernel", 0, 0}, {"conv3x3s2_kernel", kFlopS2, kBoth}, {"conv3x3_p4_kernel", kFlop3x3, kBoth}};
+    {"smpl_extra_joints_kernel", 0, kBoth}, {"relate_project_kernel+relate_attend_kernel", 0, 0}, {"conv3x3s2_kernel", kFlopS2, kBoth}, {"conv3x3_p4_kernel", kFlop3x3, kBoth},
+    {"conv_basic_block_kernel", 2.0 * kFlop3x3, kBoth}};
 
 int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
 const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].name : nullptr; }

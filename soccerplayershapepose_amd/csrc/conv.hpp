@@ -70,6 +70,12 @@ int launch_conv_s2rs(const ConvArgs& a, int num_cus, hipStream_t stream);
 bool conv_wres_supported(const ConvArgs& a);
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);
 
+// conv_fb.hip (round 5): one launch per BasicBlock of layer1 -- conv1 + ReLU into LDS, conv2 + residual + ReLU out of it, both
+// convolutions' weights stationary in registers.  in / out [B][66][66][64] (distinct); wf = pack_block_fragments' image on the device
+void pack_block_fragments(const uint16_t* w1, const uint16_t* w2, std::vector<uint16_t>& out);
+int launch_conv_fb(const uint16_t* in, const uint16_t* wf, const float* bias1, const float* bias2, uint16_t* out, int B, int f16,
+                   int max_workgroups, hipStream_t stream);
+
 // conv_stem.hip: conv1 + BN + ReLU + max-pool in one kernel: native input [B][262][264][18] -> pooled map [B][66][66][64];
 // its first workgroup also zeroes `nzero` words at `zero_words` (the counters of the forward's later kernels; may be NULL)
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,

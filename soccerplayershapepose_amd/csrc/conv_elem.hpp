@@ -23,6 +23,30 @@ struct Elem<false> {
     static __device__ __forceinline__ f4 mfma(V a, V b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x8, a), __builtin_bit_cast(x8, b), c, 0, 0, 0);
     }
+    // c += A . B with the A operand read STRAIGHT from the accumulation register file.  For register-stationary weights beyond the 256
+    // architectural VGPRs: hipcc homes such long-lived fragments in AGPRs and copies them back in front of every MFMA (four
+    // v_accvgpr_read per fragment use: 578 of them per 320 MFMAs in conv_s2rs, round 4) although the matrix core takes AGPR operands.
+    // Inline asm: nothing inside is padded by hipcc -- callers keep VALU writes of c two states away and put >= 18 wait states between
+    // the last MFMA and the first VALU read of c (cdna_hip_programming.md 5.7).
+    template <typename V>
+    static __device__ __forceinline__ void mfma_agpr(f4& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+    }
+    template <typename V>
+    static __device__ __forceinline__ void mfma_vgpr(f4& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+    // the FIRST product of an accumulation chain: c = A . B + c0 with c0 in registers of its own (a bias) or the constant 0.  An
+    // accumulator initialised by VALU moves is a hazard in front of an asm MFMA: hipcc rematerialises the moves right in front of
+    // their first use and pads nothing (round 5, conv_s2rs: sums off in the fourth digit).
+    template <typename V>
+    static __device__ __forceinline__ void mfma_agpr_from(f4& c, const V& a, const V& b, const f4& c0) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(c) : "a"(a), "v"(b), "v"(c0));
+    }
+    template <typename V>
+    static __device__ __forceinline__ void mfma_agpr_zero(f4& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(b));
+    }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {
         f2 v = {a, b};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, x2));
@@ -42,6 +66,25 @@ struct Elem<true> {
     static __device__ __forceinline__ f4 mfma(V a, V b, f4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(x8, a), __builtin_bit_cast(x8, b), c, 0, 0, 0);
     }
+    template <typename V>
+    static __device__ __forceinline__ void mfma_agpr(f4& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+    }
+    template <typename V>
+    static __device__ __forceinline__ void mfma_vgpr(f4& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+    // the FIRST product of an accumulation chain: c = A . B + c0 with c0 in registers of its own (a bias) or the constant 0.  An
+    // accumulator initialised by VALU moves is a hazard in front of an asm MFMA: hipcc rematerialises the moves right in front of
+    // their first use and pads nothing (round 5, conv_s2rs: sums off in the fourth digit).
+    template <typename V>
+    static __device__ __forceinline__ void mfma_agpr_from(f4& c, const V& a, const V& b, const f4& c0) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(c) : "a"(a), "v"(b), "v"(c0));
+    }
+    template <typename V>
+    static __device__ __forceinline__ void mfma_agpr_zero(f4& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(b));
+    }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {
         f2 v = {a, b};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, x2));      // round-to-nearest-even
@@ -50,5 +93,12 @@ struct Elem<true> {
     static __device__ __forceinline__ float hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
     static __device__ __forceinline__ float one(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
 };
+
+// Between the last asm MFMA of a chain and the first VALU / LDS / store read of its result: the wait states hipcc would have padded
+// (18 cover every XDL op), tied to the accumulators by operands so that no reader is scheduled above them.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_drain8(f4_t& a, f4_t& b, f4_t& c, f4_t& d, f4_t& e, f4_t& f, f4_t& g, f4_t& h) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
 
 }  // namespace spsp

@@ -194,23 +194,25 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
         const uint32_t bufo = (uint32_t)((t & 1) * kPatch);
 
         f32x4 acc[4][4], acc2[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         bf16x8 xfr[2][4];
 #define RS_SB __builtin_amdgcn_sched_barrier(0);
 #define RS_RX(SET, J, CB, DY) xfr[SET][J] = lds_read_b128(xrel[CB][(J) + (DY)] + bufo);
 #define RS_M2(S, SET, ACC, I, J)                                                                        \
         RS_SB                                                                                           \
-        ACC[I][J] = Elem<F16>::mfma(wreg[S][I], xfr[SET][J], ACC[I][J]);                                \
-        ACC[I][(J) + 1] = Elem<F16>::mfma(wreg[S][I], xfr[SET][(J) + 1], ACC[I][(J) + 1]);              \
+        if constexpr (RS_FIRST) {    /* a chain's first K-step: C = 0 in the instruction, no VALU zeroing (conv_elem.hpp) */ \
+            Elem<F16>::mfma_agpr_zero(ACC[I][J], wreg[S][I], xfr[SET][J]);                              \
+            Elem<F16>::mfma_agpr_zero(ACC[I][(J) + 1], wreg[S][I], xfr[SET][(J) + 1]);                  \
+        } else {                                                                                        \
+            Elem<F16>::mfma_agpr(ACC[I][J], wreg[S][I], xfr[SET][J]);                                   \
+            Elem<F16>::mfma_agpr(ACC[I][(J) + 1], wreg[S][I], xfr[SET][(J) + 1]);                       \
+        }                                                                                               \
         RS_SB
         // One K-step S: its 16 MFMAs (pixel fragments in set SET, into ACC) with the four pixel-fragment reads of the step
         // after next-in-the-other-set (combo NCB, row shift NDY; skipped unless HASN) beside the first four MFMA pairs.
 #define RS_STEP(S, SET, ACC, HASN, NSET, NCB, NDY)                                                      \
     {                                                                                                   \
+        constexpr bool RS_FIRST = (S) == 0 || (S) == 1;      /* ring step 0 opens the main chain, 1 (the downsample) the second */ \
         if (HASN) { RS_RX(NSET, 0, NCB, NDY) }                                                          \
         RS_M2(S, SET, ACC, 0, 0)                                                                        \
         if (HASN) { RS_RX(NSET, 1, NCB, NDY) }                                                          \
@@ -237,11 +239,13 @@ __global__ __launch_bounds__(256) void conv3x3s2_kernel(const ConvArgs a, const 
         RS_STEP(7, 0, acc, true, 1, 5, 0)        // tap (2,0)                         -> reads tap (0,2)
         RS_STEP(8, 1, acc, true, 0, 5, 1)        // tap (0,2)                         -> reads tap (2,2)
         RS_STEP(9, 0, acc, true, 1, 0, 0)        // tap (2,2)                         -> reads the centre tap's pixels again
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         RS_STEP(1, 1, acc2, false, 0, 0, 0)      // downsample
+        // round 5: the MFMAs are inline asm with the weight fragment read straight from the accumulation register file (hipcc copied
+        // AGPR-resident fragments back in front of every MFMA: 578 v_accvgpr_read per 320 MFMAs); the wait between the last MFMA and
+        // the first read of its result is spelled out
+        mfma_drain8(acc2[0][0], acc2[0][1], acc2[0][2], acc2[0][3], acc2[1][0], acc2[1][1], acc2[1][2], acc2[1][3]);
+        asm volatile("" : "+v"(acc2[2][0]), "+v"(acc2[2][1]), "+v"(acc2[2][2]), "+v"(acc2[2][3]), "+v"(acc2[3][0]), "+v"(acc2[3][1]), "+v"(acc2[3][2]), "+v"(acc2[3][3]));
+        __builtin_amdgcn_sched_barrier(0);
 #undef RS_STEP
 #undef RS_M2
 #undef RS_RX

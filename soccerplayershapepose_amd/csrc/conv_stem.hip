@@ -145,9 +145,12 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
             dma16(wb + (size_t)(row * 112 + (c ^ (row & 15))) * 16, smem + kWOff + p * 1024);
         }
     }
-    float4 bias_r[2];
+    f32x4 bias_v[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) bias_r[i] = *reinterpret_cast<const float4*>(a.bias + 32 * h + 16 * i + 4 * fq);
+    for (int i = 0; i < 2; ++i) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + 32 * h + 16 * i + 4 * fq);
+        bias_v[i] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- this wave's weights as MFMA A-fragments, resident for the whole kernel: row 32h + 16i + frow, chunk 4g + fq ----
@@ -158,13 +161,13 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 #pragma unroll
         for (int g3 = 0; g3 < 4; ++g3)
             wa[g3] = smem_base + kWOff + (32 * h + frow) * 1792 + 64 * (g3 ^ (frow >> 2)) + 16 * (fq ^ (frow & 3));
-        // four fragments AND their wait in one asm statement: hipcc takes an asm output as written when the statement ends
-        // and moves most of these long-lived fragments to accumulator registers right behind it -- with the wait in a
-        // later statement it copied registers the LDS had not filled yet
+        // four fragments AND their wait in one asm statement (hipcc takes an asm output as written when the statement ends), read
+        // STRAIGHT INTO accumulation registers (round 5: the MFMAs take them from there; defined in VGPRs hipcc kept half of them
+        // there and copied a fragment over in front of every use -- 228 v_accvgpr_write per step)
 #define STEM_WR4(I, G)                                                                                    \
         asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"                 \
                      "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)" \
-                     : "=&v"(wreg[I][G]), "=&v"(wreg[I][(G) + 1]), "=&v"(wreg[I][(G) + 2]), "=&v"(wreg[I][(G) + 3]) \
+                     : "=&a"(wreg[I][G]), "=&a"(wreg[I][(G) + 1]), "=&a"(wreg[I][(G) + 2]), "=&a"(wreg[I][(G) + 3]) \
                      : "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "n"((I) * 16 * 1792 + ((G) >> 2) * 256) : "memory");
         STEM_WR4(0, 0) STEM_WR4(0, 4) STEM_WR4(0, 8) STEM_WR4(0, 12) STEM_WR4(0, 16) STEM_WR4(0, 20) STEM_WR4(0, 24)
         STEM_WR4(1, 0) STEM_WR4(1, 4) STEM_WR4(1, 8) STEM_WR4(1, 12) STEM_WR4(1, 16) STEM_WR4(1, 20) STEM_WR4(1, 24)
@@ -198,11 +201,8 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 
         // the accumulators START at the folded BN bias (accumulator element e of tile (i, j) = channel 32 h + 16 i + 4 fq + e):
         // 64 additions less in the pooling phase, which a lone wave issues at 4-5 cycles each
+        // (since round 5 not by moves: sub-step 0's MFMAs take the bias registers as their C operand -- conv_elem.hpp, mfma_agpr_from)
         f32x4 acc[2][8];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{bias_r[i].x, bias_r[i].y, bias_r[i].z, bias_r[i].w};
 
         // fragment base address per kernel row: input row 2 (conv row) + kr = ring row n0 + 2r + kr
         uint32_t xa[7];
@@ -226,9 +226,14 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
         if (DIAG != 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(WAITN) : "memory");                      \
         STEM_SB                                                                                           \
         if (DIAG != 2) {                                                                                  \
-            acc[0][J] = Elem<F16>::mfma(wreg[0][G], xf[J], acc[0][J]);                                    \
-            acc[1][J] = Elem<F16>::mfma(wreg[1][G], xf[J], acc[1][J]);                                    \
-        } else { asm volatile("" : "+v"(xf[J])); }                                                        \
+            if constexpr ((G) == 0) {                                                                     \
+                Elem<F16>::mfma_agpr_from(acc[0][J], wreg[0][G], xf[J], bias_v[0]);                       \
+                Elem<F16>::mfma_agpr_from(acc[1][J], wreg[1][G], xf[J], bias_v[1]);                       \
+            } else {                                                                                      \
+                Elem<F16>::mfma_agpr(acc[0][J], wreg[0][G], xf[J]);                                       \
+                Elem<F16>::mfma_agpr(acc[1][J], wreg[1][G], xf[J]);                                       \
+            }                                                                                             \
+        } else { if constexpr ((G) == 0) { acc[0][J] = bias_v[0]; acc[1][J] = bias_v[1]; } asm volatile("" : "+v"(xf[J])); }  \
         STEM_SB
         // sub-step G; (KR1, KS1) = coordinates of sub-step G+1 (slots J >= 1 read ahead into it, slot 0 still into G)
 #define STEM_STEP(G, KR0, KS0, KR1, KS1)                                                                  \
@@ -275,6 +280,12 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
 #undef STEM_RD
 #undef STEM_SB
 
+        // (round 5: the MFMAs are inline asm with the weight fragment read straight from the accumulation file -- hipcc copied 144
+        //  AGPR-resident fragments back per step, into a loop that is bound by its issue slots; nothing inside an asm is padded, so the
+        //  wait between the last MFMA and the first VALU read of its result is spelled out)
+        mfma_drain8(acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[0][4], acc[0][5], acc[0][6], acc[0][7]);
+        asm volatile("" : "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[1][4]), "+v"(acc[1][5]), "+v"(acc[1][6]), "+v"(acc[1][7]));
+        __builtin_amdgcn_sched_barrier(0);
         SSTAMP(3);
         // ---- horizontal 3 -> 1 max in registers.  Round to the element type FIRST, then ReLU on the packed pairs (all monotone:
         // max commutes with them; as SIGNED 16-bit integers every negative value, -0 included, is below +0 = 0, so

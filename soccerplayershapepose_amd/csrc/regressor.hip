@@ -292,6 +292,8 @@ struct spsp_regressor {
     int f16;               // 0: bf16 storage + bf16 MFMA (precision 0), 1: fp16 storage + f16 MFMA (precision 1)
     uint16_t* w[SPSP_NUM_CONVS];
     float* bias[SPSP_NUM_CONVS];
+    uint16_t* wfb[2];      // layer1's two BasicBlocks: both convolutions' weights as register-order MFMA fragments (conv_fb.hip)
+    bool use_fb = true;    // layer1: one launch per BasicBlock (conv_fb.hip); off: two conv_wres launches per block (SPSP_DEBUG_PLAN_FB)
     float *w1f, *w13, *w2, *w3;   // IEF weights in the fused kernel's form (see ief_fused_kernel)
     float *cvec, *b2, *p0;
     float* init_params;
@@ -337,7 +339,7 @@ struct spsp_regressor {
     // workgroup does, with the tile-scheduler words); an IEF call uses them up.  spsp_regressor_ief on a handle whose counters are
     // not fresh (IEF run twice on the same features, IEF before any backbone) zeroes its eight lines itself with a memset node.
     bool ief_counters_fresh = false;
-    int ief_block = 32;                 // players per IEF block (64 workgroups that hand off to each other): 32, or 16 = two independent halves
+    int ief_block = 16;                 // players per IEF block (64 workgroups that hand off to each other): 32, or 16 = two independent halves
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
 
@@ -451,6 +453,15 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         }
         TRY(r->pool.upload(&r->w[ci], wt.data(), wt.size()));
         TRY(r->pool.upload(&r->bias[ci], bias.data(), bias.size()));
+        if (ci >= 1 && ci <= 4) {                      // layer1: convs 1, 2 = block 0; 3, 4 = block 1
+            static thread_local std::vector<uint16_t> first;
+            if (ci & 1) first = wt;
+            else {
+                std::vector<uint16_t> frag;
+                pack_block_fragments(first.data(), wt.data(), frag);
+                TRY(r->pool.upload(&r->wfb[(ci - 1) / 2], frag.data(), frag.size()));
+            }
+        }
     }
     {   // fc1 [512][669] split by input columns (ief_module.py:55 concatenates [feat | params]); products in fp64
         const int it_n = w->ief_iters > 0 ? w->ief_iters : 1;
@@ -615,7 +626,16 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
     for (int L = 0; L < 4; ++L) {
         const int S = kLayerS[L];
         uint16_t *ba = r->l[L][0], *bb = r->l[L][1], *bc = r->l[L][2];
-        if (L == 0) {
+        if (L == 0 && r->use_fb) {
+            // one launch per BasicBlock: out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), the intermediate map stays in LDS
+            const int wgs = r->wres_cu_div >= 32 ? r->wres_cu_div : ctx->num_cus / r->wres_cu_div;
+            { ProfScope ps(ctx, kKConvFb, st, true);
+              TRY(launch_conv_fb(x, r->wfb[0], r->bias[ci], r->bias[ci + 1], bb, B, r->f16, wgs, st)); }
+            { ProfScope ps(ctx, kKConvFb, st, true);
+              TRY(launch_conv_fb(bb, r->wfb[1], r->bias[ci + 2], r->bias[ci + 3], bc, B, r->f16, wgs, st)); }
+            ci += 4;
+            x = bc;
+        } else if (L == 0) {
             TRY(run_conv(ctx, r, ci, x, xs, 1, ba, nullptr, 1, B, nullptr, st, L));         // t   = relu(bn1(conv1(x)))
             TRY(run_conv(ctx, r, ci + 1, ba, S, 1, bb, x, 1, B, nullptr, st, L));           // out = relu(bn2(conv2(t)) + x)
             ci += 2;
@@ -733,6 +753,7 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             SPSP_REQUIRE(value == 16 || value == 32, "spsp_regressor_debug: IEF blocks of %d players (16 or 32)", value);
             r->ief_block = value;
             return SPSP_OK;
+        case SPSP_DEBUG_PLAN_FB: r->use_fb = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)

@@ -378,6 +378,35 @@ def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
             assert torch.equal(got[2][1][0], got[6][1][0])
 
 
+def test_layer1_basic_block_in_one_launch_is_bit_identical_to_two_launches(dev):
+    """csrc/conv_fb.hip (round 5): a BasicBlock of layer1 as ONE launch -- conv1 + ReLU into LDS on the 18 x 18 pixels conv2 needs
+    (zeros outside the image), conv2 + residual + ReLU out of LDS, both convolutions' weights stationary in registers -- against the
+    two conv_wres.hip launches per block it replaces (`SPSP_DEBUG_PLAN_FB` = 0).  Same products in the same order with the same
+    rounding points (the intermediate map is rounded to the element type either way): layer1's map and everything behind it equal
+    bit for bit, at B = 32 (two tiles per workgroup), 22 (352 tiles: ragged ranges), 3 and 1, both element types, chip-filling and
+    narrow grids (eight tiles per resident weight set)."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec, batches in (('f16', (32, 22, 3, 1)), ('bf16', (32, 5))):
+        for B in batches:
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=70 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = {}
+            for fb, div in ((0, 1), (1, 1), (1, 4), (1, 16)):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_FB, fb), 'debug')
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_WRES_CUS, div), 'debug')
+                out = [t.clone() for t in reg(native)] + [reg.read_stage(s_, B).clone() for s_ in (2, 5)]
+                torch.cuda.synchronize()
+                reg.check_status()
+                got[(fb, div)] = out
+            for key, other in got.items():
+                for a, b in zip(got[(0, 1)], other):
+                    assert torch.isfinite(a).all() and torch.equal(a, b), (prec, B, key, (a - b).abs().max().item())
+
+
 def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
     """Plan "throughput" launches the persistent kernels narrow -- layer1 (conv_wres.hip) on a quarter of the CUs, the stem
     (conv_stem.hip) in bands of up to 64 conv rows, layer2 / layer3 (conv_p4.hip) on 64 workgroups that walk 4 / 2 tiles each
