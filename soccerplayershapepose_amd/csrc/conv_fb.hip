@@ -32,6 +32,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+// max(x, +0) on both 16-bit floats of a pair, either element type: as SIGNED 16-bit integers every negative value (-0 included) is
+// below +0 = 0.  Rounding to the element type and ReLU commute (both monotone), so ReLU runs on the packed pair: one instruction
+// where the fp32 form takes two (conv_stem.hip does the same).
+__device__ __forceinline__ uint32_t pk_relu16(uint32_t x) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), i16x2{0, 0}));
+}
+
 constexpr int kPitch = 20, kPixB = 128;
 constexpr int kPatchB = kPitch * kPitch * kPixB;       // 51 200: 50 LDS-DMA pieces of 8 pixels
 constexpr int kInterOff = 2 * kPatchB;                 // two patch buffers, then the intermediate grid
@@ -129,7 +137,7 @@ __device__ __forceinline__ void fb_step(f32x4 (&acc)[2][4], bf16x8 (&xf)[2][4], 
 }
 
 #ifdef SPSP_CONV_STAMPS
-#define FSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0 && t == t_begin + 1) a.dbg[i] = __builtin_amdgcn_s_memtime()
+#define FSTAMP(i) if (a.dbg && blockIdx.x == 8 && tid == 0 && ntile_done == 1) a.dbg[i] = __builtin_amdgcn_s_memtime()
 #define FSTAMPK(i) if (a.dbg && blockIdx.x == 8 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime()
 #else
 #define FSTAMP(i)
@@ -145,13 +153,15 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
     const int frow = lane & 15, fq = lane >> 4;
     FSTAMPK(0);
     // Workgroups b, b + 8, ... share an XCD (round-robin dispatch; speed only): they take CONSECUTIVE tile ranges, so that the halos
-    // neighbouring tiles share come out of one L2
+    // neighbouring tiles share come out of one L2.  (Tiles from per-XCD device counters, conv_wres.hip's dynamic scheduler, were built
+    // and measured in round 5: 130.7 k players/s in the four-slot pipeline with either, +0.5 us per launch alone -- fixed ranges stay.)
     const int G = (int)gridDim.x;
     int L = (int)blockIdx.x;
     if ((G & 7) == 0) L = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
-    const int t_begin = L * a.tiles_per_wg;
-    const int t_end = t_begin + a.tiles_per_wg < a.ntiles ? t_begin + a.tiles_per_wg : a.ntiles;
-    if (t_begin >= t_end) return;
+    int t = L * a.tiles_per_wg;
+    const int t_end = t + a.tiles_per_wg < a.ntiles ? t + a.tiles_per_wg : a.ntiles;
+    if (t >= t_end) return;
+    int ntile_done = 0;
 
     // ---- LDS-DMA of a tile's patch: piece j = patch pixels 8 j .. 8 j + 7 (wave w: j = w, w + 4, ...); lane l feeds pixel
     //      p = 8 j + l / 8, physical 16-byte chunk l % 8 = logical chunk (l % 8) ^ (p & 7).  Rows / columns beyond the buffer's
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
         for (int i = 0; i < 2; ++i) wA[s][i] = w1[(s * 2 + i) * 64];
     __builtin_amdgcn_sched_barrier(0);
     {
-        const int img = t_begin >> 4, r = t_begin & 15;
+        const int img = t >> 4, r = t & 15;
 #pragma unroll
         for (int i = 0; i < kPiecesPerWave; ++i) issue_piece(i, img, (r >> 2) * 16, (r & 3) * 16, 0);
     }
@@ -211,7 +221,16 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
     }
     // intermediate pixel m = 16 (12 ph + T') + frow: its 16 bytes = channels 32 ch + 8 fq .. + 7 (logical chunk 4 ch + fq)
     const uint32_t e0 = smem_base + kInterOff + ph * 12 * 2048 + frow * kPixB + (((ch * 4 + fq) ^ (frow & 7)) * 16);
-    const int m0 = 192 * ph + frow;
+    // ... zeros where it lies outside the image: grid row 0 / 17 at the image's top / bottom border, column 0 / 17 at its left / right
+    // one.  Four flag bits per tile T' (bit 0 row 0, 1 row 17, 2 column 0, 3 column 17) of this lane's pixel, twelve tiles in two words.
+    uint32_t edge_lo = 0u, edge_hi = 0u;
+#pragma unroll
+    for (int tp = 0; tp < 12; ++tp) {
+        const int m = 192 * ph + frow + 16 * tp;
+        const int rr = (m * 205) >> 12, cc = m - kPitch * rr;
+        const uint32_t f = (rr == 0 ? 1u : 0u) | (rr == 17 ? 2u : 0u) | (cc == 0 ? 4u : 0u) | (cc == 17 ? 8u : 0u);
+        if (tp < 8) edge_lo |= f << (4 * tp); else edge_hi |= f << (4 * (tp - 8));
+    }
     // residual of output pixel (8 ph + oy', frow) = patch pixel (oy + 2, frow + 2), the same 16 bytes; two swizzle keys by row parity
     uint32_t rr0[2];
 #pragma unroll
@@ -220,17 +239,18 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
     const int lane_out = ((8 * ph + 1) * 66 + frow + 1) * 64 + 32 * ch + 8 * fq;      // (elements; + tile origin)
 
     int cur = 0;
-    for (int t = t_begin; t < t_end; ++t, cur ^= 1) {
+    for (;; cur ^= 1) {
         const int img = t >> 4, r = t & 15;
         const int y0 = (r >> 2) * 16, x0 = (r & 3) * 16;
         // this tile's patch: this wave's pieces have landed (they are older than the eight stores of the previous tile), then everybody's;
         // every wave has left the other patch buffer and the intermediate grid
         FSTAMP(1);
-        if (t == t_begin) wait_vmcnt<0>(); else wait_vmcnt<8>();
+        if (ntile_done == 0) wait_vmcnt<0>(); else wait_vmcnt<8>();
         __builtin_amdgcn_s_barrier();
         FSTAMP(2);
         const bool has_next = t + 1 < t_end;
         const int nimg = (t + 1) >> 4, nr = (t + 1) & 15, ny0 = (nr >> 2) * 16, nx0 = (nr & 3) * 16;
+        const uint32_t border = (y0 == 0 ? 1u : 0u) | (y0 == 48 ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 == 48 ? 8u : 0u);
         uint32_t ad1[6][2];
 #pragma unroll
         for (int di = 0; di < 6; ++di) {
@@ -261,13 +281,12 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
         // accumulators -> ReLU -> 16-bit -> the intermediate grid (zeros outside the image); T' = 4 PASS + j
 #define FB_EPI1_J(PASS, J)                                                                                               \
         if (!(ph == 1 && 4 * (PASS) + (J) == 11)) {          /* (tile 23: beyond the grid) */                            \
-            const int m_ = m0 + 16 * (4 * (PASS) + (J));                                                                 \
-            const int rr_ = (m_ * 205) >> 12, cc_ = m_ - kPitch * rr_;                                                   \
-            const bool in_ = (unsigned)(y0 - 1 + rr_) < 64u && (unsigned)(x0 - 1 + cc_) < 64u;                           \
+            /* outside the image = on an edge row / column of the grid (this lane's four flag bits of tile T') at an image border */ \
+            const bool out_ = (((4 * (PASS) + (J)) < 8 ? edge_lo >> (4 * ((4 * (PASS) + (J)) & 7)) : edge_hi >> (4 * ((4 * (PASS) + (J)) & 7))) & border) != 0u; \
             const f32x4 lo_ = acc[0][J], hi_ = acc[1][J];                                                                \
-            u32x4 v_ = u32x4{Elem<F16>::pack2(fmaxf(lo_[0], 0.f), fmaxf(lo_[1], 0.f)), Elem<F16>::pack2(fmaxf(lo_[2], 0.f), fmaxf(lo_[3], 0.f)),  \
-                             Elem<F16>::pack2(fmaxf(hi_[0], 0.f), fmaxf(hi_[1], 0.f)), Elem<F16>::pack2(fmaxf(hi_[2], 0.f), fmaxf(hi_[3], 0.f))}; \
-            if (!in_) v_ = u32x4{0u, 0u, 0u, 0u};                                                                        \
+            u32x4 v_ = u32x4{pk_relu16(Elem<F16>::pack2(lo_[0], lo_[1])), pk_relu16(Elem<F16>::pack2(lo_[2], lo_[3])),  \
+                             pk_relu16(Elem<F16>::pack2(hi_[0], hi_[1])), pk_relu16(Elem<F16>::pack2(hi_[2], hi_[3]))}; \
+            if (out_) v_ = u32x4{0u, 0u, 0u, 0u};                                                                        \
             /* (inline asm: behind a plain LDS store hipcc waits vmcnt(0) -- for the next tile's LDS-DMA, which it cannot tell apart) */ \
             asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(e0), "v"(v_), "n"((4 * (PASS) + (J)) * 2048) : "memory");    \
         }
@@ -309,12 +328,13 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
             _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                           \
                 const uint4 rq_ = __builtin_bit_cast(uint4, res_[j_]);                                                   \
                 const f32x4 lo_ = acc[0][j_], hi_ = acc[1][j_];                                                          \
-                const float v0_ = fmaxf(lo_[0] + Elem<F16>::lo(rq_.x), 0.f), v1_ = fmaxf(lo_[1] + Elem<F16>::hi(rq_.x), 0.f); \
-                const float v2_ = fmaxf(lo_[2] + Elem<F16>::lo(rq_.y), 0.f), v3_ = fmaxf(lo_[3] + Elem<F16>::hi(rq_.y), 0.f); \
-                const float v4_ = fmaxf(hi_[0] + Elem<F16>::lo(rq_.z), 0.f), v5_ = fmaxf(hi_[1] + Elem<F16>::hi(rq_.z), 0.f); \
-                const float v6_ = fmaxf(hi_[2] + Elem<F16>::lo(rq_.w), 0.f), v7_ = fmaxf(hi_[3] + Elem<F16>::hi(rq_.w), 0.f); \
+                const float v0_ = lo_[0] + Elem<F16>::lo(rq_.x), v1_ = lo_[1] + Elem<F16>::hi(rq_.x);                    \
+                const float v2_ = lo_[2] + Elem<F16>::lo(rq_.y), v3_ = lo_[3] + Elem<F16>::hi(rq_.y);                    \
+                const float v4_ = hi_[0] + Elem<F16>::lo(rq_.z), v5_ = hi_[1] + Elem<F16>::hi(rq_.z);                    \
+                const float v6_ = hi_[2] + Elem<F16>::lo(rq_.w), v7_ = hi_[3] + Elem<F16>::hi(rq_.w);                    \
                 *reinterpret_cast<uint4*>(out_t + (size_t)(4 * (PASS) + j_) * (66 * 64)) =                                \
-                    make_uint4(Elem<F16>::pack2(v0_, v1_), Elem<F16>::pack2(v2_, v3_), Elem<F16>::pack2(v4_, v5_), Elem<F16>::pack2(v6_, v7_)); \
+                    make_uint4(pk_relu16(Elem<F16>::pack2(v0_, v1_)), pk_relu16(Elem<F16>::pack2(v2_, v3_)),            \
+                               pk_relu16(Elem<F16>::pack2(v4_, v5_)), pk_relu16(Elem<F16>::pack2(v6_, v7_)));           \
             }                                                                                                            \
         }
         FB_FIRST(1, ad2)
@@ -323,6 +343,9 @@ __global__ __launch_bounds__(256, 1) void conv_basic_block_kernel(const FbArgs a
         FB_PASS(1, 1, 2, wB, ad2)
         FB_EPI2(1)
         FSTAMP(5);
+        ++ntile_done;
+        if (!has_next) break;
+        ++t;
 #undef FB_EPI2
 #undef FB_S_DMA
 #undef FB_EPI1

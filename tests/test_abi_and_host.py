@@ -168,7 +168,8 @@ def test_public_header_is_valid_c99_and_a_c_host_links_against_the_library(tmp_p
     assert out.stdout.startswith('spsp') and 'NULL handle' in out.stdout
 
 
-def test_conv_wres_tile_id_agpr_is_untouched_while_its_atomic_is_in_flight():
+@pytest.mark.parametrize('src,wait', [('conv_wres', 's_waitcnt vmcnt(0)')])
+def test_tile_id_agpr_is_untouched_while_its_atomic_is_in_flight(src, wait):
     """conv_wres.hip fetches the id of the tile after next with a returning atomic whose AGPR destination is read a whole
     tile later (`s_waitcnt vmcnt(0); v_accvgpr_read_b32`).  hipcc considers the asm output written when the statement ends,
     so nothing but the register allocator's lack of a reason keeps it from copying or reusing that register before the
@@ -180,8 +181,8 @@ def test_conv_wres_tile_id_agpr_is_untouched_while_its_atomic_is_in_flight():
     if shutil.which('hipcc') is None:
         pytest.skip('no hipcc')
     csrc = os.path.join(ROOT, 'soccerplayershapepose_amd', 'csrc')
-    subprocess.check_call(['make', '-C', csrc, 'conv_wres.s'], stdout=subprocess.DEVNULL)
-    text = open(os.path.join(csrc, 'conv_wres.s')).read()
+    subprocess.check_call(['make', '-C', csrc, src + '.s'], stdout=subprocess.DEVNULL)
+    text = open(os.path.join(csrc, src + '.s')).read()
     kernels = [k for k in re.split(r'\n\s*s_endpgm', text) if 'global_atomic_add a' in k]
     assert kernels, 'no kernel with the in-flight AGPR atomic found (did the scheduler change?)'
     checked = 0
@@ -205,7 +206,7 @@ def test_conv_wres_tile_id_agpr_is_untouched_while_its_atomic_is_in_flight():
                 if re.match(r'global_atomic_add ' + reg + ',', ins[j]):
                     continue
                 assert re.match(r'v_accvgpr_read_b32 v\d+, ' + reg + '$', ins[j]), f'{reg} touched before its atomic returned: "{ins[j]}"'
-                assert ins[j - 1].startswith('s_waitcnt vmcnt(0)'), f'{reg} read without the wait in front: "{ins[j - 1]}" / "{ins[j]}"'
+                assert ins[j - 1].startswith(wait), f'{reg} read without the wait in front: "{ins[j - 1]}" / "{ins[j]}"'
                 checked += 1
                 break
             else:

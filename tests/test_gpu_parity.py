@@ -1426,7 +1426,7 @@ def test_player_pipeline_keeps_freshly_allocated_inputs_alive_across_streams(reg
 
 
 def test_smpl_forward_is_bit_stable_next_to_convolutions_on_other_streams(regressor_sd_np, smpl_model_np, dev):
-    """Regression test for a cross-stream corruption found with tools/race_hunt2.py: with packed-fp32 VALU ops
+    """Regression test for a cross-stream corruption found with tools/attic/race_hunt2.py: with packed-fp32 VALU ops
     (`v_pk_fma_f32 ... op_sel`) in the skin kernel, ~35 % of SMPL forwards came out with wrong y-coordinates in
     lanes 48-63 of even players whenever MFMA / LDS-DMA convolution workgroups of another stream shared the CU.
     The library is built without packed-fp32 ops (csrc/Makefile); every forward must equal the serial result."""
