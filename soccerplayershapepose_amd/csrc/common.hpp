@@ -103,6 +103,8 @@ enum KernelId {
     kKIefFc, kKIefMisc, kKProxyPack, kKProxyBuild, kKRot6d, kKFit, kKSmplChain, kKSmplSkin, kKSmplJoints, kKRelate,
     kKConvS2,          // conv3x3s2_kernel (the three 3x3 / 2 convs + their fused 1x1 / 2 downsamples, parity-plane patch)
     kKConvP4,          // conv3x3_p4_kernel (3x3 / 1 of layer2 and, plan "throughput", layer3: 256-pixel tiles, no K split, producer waves)
+    kKConvS2q,         // conv3x3s2q_kernel (layer2.0's stride-2 pair, all output channels per workgroup, weights in registers)
+    kKConvRs,          // conv3x3rs_kernel (plan "throughput": layer2's 3x3 / 1 convs, a channel block's weights in registers, persistent)
     kKConvFb,          // conv_basic_block_kernel (layer1: a whole BasicBlock per launch, weights in registers, intermediate tile in LDS)
     kKNumKernels
 };

@@ -53,7 +53,7 @@ static const KernelRow kKernels[spsp::kKNumKernels] = {
     {"ief_fused_kernel", 0, kBoth}, {"ief_init_only_kernel", 0, 0}, {"proxy_pack_kernel", 0, 0}, {"proxy_build_kernel", 0, 0},
     {"rot6d_kernel", 0, 0}, {"fit_kernel2", 0, kBoth}, {"smpl_chain_kernel", 0, 0}, {"smpl_skin_kernel", 0, kBoth},
     {"smpl_extra_joints_kernel", 0, kBoth}, {"relate_project_kernel+relate_attend_kernel", 0, 0}, {"conv3x3s2_kernel", kFlopS2, kBoth}, {"conv3x3_p4_kernel", kFlop3x3, kBoth},
-    {"conv_basic_block_kernel", 2.0 * kFlop3x3, kBoth}};
+    {"conv3x3s2q_kernel", kFlopS2, kBoth}, {"conv3x3rs_kernel", kFlop3x3, kTP}, {"conv_basic_block_kernel", 2.0 * kFlop3x3, kBoth}};
 
 int spsp_profile_num_kernels(void) { return spsp::kKNumKernels; }
 const char* spsp_profile_kernel_name(int id) { return (id >= 0 && id < spsp::kKNumKernels) ? kKernels[id].name : nullptr; }

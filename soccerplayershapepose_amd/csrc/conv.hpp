@@ -66,6 +66,19 @@ int launch_conv_s2(const ConvArgs& a, hipStream_t stream);
 bool conv_s2rs_supported(const ConvArgs& a);
 int launch_conv_s2rs(const ConvArgs& a, int num_cus, hipStream_t stream);
 
+// conv_s2q.hip (round 5): layer2.0's pair with ALL 128 output channels in one workgroup (planes staged once), wave = a 32-channel
+// quarter over the whole K, weights in registers (AGPR-operand MFMAs), 4 x 16-pixel tiles, no K split.  in [B][66][66][64], out / out2
+// [B][34][34][128]; wf = pack_s2q_fragments' image on the device
+void pack_s2q_fragments(const uint16_t* w, const uint16_t* w2, std::vector<uint16_t>& out);
+int launch_conv_s2q(const uint16_t* in, const uint16_t* wf, const float* bias, const float* bias2, uint16_t* out, uint16_t* out2, int B,
+                    int f16, int relu, int max_workgroups, hipStream_t stream);
+
+// conv_rs.hip (round 5, plan "throughput"): layer2's 3x3 / 1 convolutions (128 -> 128, 32 x 32 maps) with a 64-channel block's weights
+// stationary in registers, persistent over 8 x 16-pixel tiles.  in / out / res [B][34][34][128]; wf = pack_rs_fragments' image
+void pack_rs_fragments(const uint16_t* w, std::vector<uint16_t>& out);
+int launch_conv_rs(const uint16_t* in, const uint16_t* wf, const float* bias, const uint16_t* res, uint16_t* out, int B, int f16, int relu,
+                   int max_workgroups, hipStream_t stream);
+
 // conv_wres.hip: 3x3 stride-1 64->64 convs (layer1) with all nine weight slabs resident in LDS, persistent workgroups
 bool conv_wres_supported(const ConvArgs& a);
 int launch_conv_wres(const ConvArgs& a, int num_cus, hipStream_t stream);
@@ -79,6 +92,6 @@ int launch_conv_fb(const uint16_t* in, const uint16_t* wf, const float* bias1, c
 // conv_stem.hip: conv1 + BN + ReLU + max-pool in one kernel: native input [B][262][264][18] -> pooled map [B][66][66][64];
 // its first workgroup also zeroes `nzero` words at `zero_words` (the counters of the forward's later kernels; may be NULL)
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t stream, int rows_per_band = 0);
+                     unsigned int* zero_words, int nzero, hipStream_t stream, int rows_per_band = 0, bool mfma32 = false);
 
 }  // namespace spsp

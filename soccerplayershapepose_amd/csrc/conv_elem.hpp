@@ -47,6 +47,17 @@ struct Elem<false> {
     static __device__ __forceinline__ void mfma_agpr_zero(f4& c, const V& a, const V& b) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(b));
     }
+    // the 32 x 32 x 16 shape (one MFMA per 32 cycles where the 16 x 16 x 32 shape issues two: half the instructions per FLOP for a
+    // loop that is bound by its issue slots -- conv_stem.hip): 16 accumulator registers per lane, A / B fragments of 8 elements
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    template <typename V>
+    static __device__ __forceinline__ void mfma32_agpr(f16v& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+    }
+    template <typename V>
+    static __device__ __forceinline__ void mfma32_agpr_from(f16v& c, const V& a, const V& b, const f16v& c0) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(c) : "a"(a), "v"(b), "v"(c0));
+    }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {
         f2 v = {a, b};
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, x2));
@@ -84,6 +95,17 @@ struct Elem<true> {
     template <typename V>
     static __device__ __forceinline__ void mfma_agpr_zero(f4& c, const V& a, const V& b) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "v"(b));
+    }
+    // the 32 x 32 x 16 shape (one MFMA per 32 cycles where the 16 x 16 x 32 shape issues two: half the instructions per FLOP for a
+    // loop that is bound by its issue slots -- conv_stem.hip): 16 accumulator registers per lane, A / B fragments of 8 elements
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    template <typename V>
+    static __device__ __forceinline__ void mfma32_agpr(f16v& c, const V& a, const V& b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+    }
+    template <typename V>
+    static __device__ __forceinline__ void mfma32_agpr_from(f16v& c, const V& a, const V& b, const f16v& c0) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(c) : "a"(a), "v"(b), "v"(c0));
     }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {
         f2 v = {a, b};

@@ -21,6 +21,7 @@
 // conv row): acc[2][8] x f32x4.  K-step = kernel row (7 taps x 18 ch = 126 contiguous input values, padded to 128 by
 // two zero weights), 4 sub-steps of 32; pixel fragments are 8-byte aligned (pixel pitch 36 B): 2 x ds_read_b64 each.
 #include <cstdlib>
+#include <utility>
 
 #include "conv.hpp"
 #include "conv_elem.hpp"
@@ -356,13 +357,214 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
     SSTAMPK(9);
 }
 
+
+// ==== round 5: the same kernel on v_mfma_f32_32x32x16 ==========================================================================
+// The K loop above is bound by its ISSUE slots: with one wave per SIMD an MFMA holds the vector issue for 8 of its 16 cycles, and a
+// slot's two ds_read_b64, its counted wait and its two MFMAs take ~41 cycles where the matrix pipe needs 32 (stamps: 9.3 k cycles per
+// step for 7.2 k of MFMA; round 4 showed that nothing can ride in that loop).  The 32 x 32 x 16 shape does the same FLOPs with ONE
+// MFMA per 32 cycles: half the MFMA issue, the same two reads -- the slot fits.  What changes:
+//   * wave tile = 32 channels x 128 conv columns = four 32 x 32 tiles (16 accumulator registers each); a K sub-step is 16 deep
+//     (56 per conv row), the 56 weight fragments are 224 AGPRs as before;
+//   * lane l of a pixel tile holds conv column 2 (l & 15) + ((l >> 4) & 1): even columns in the even 16-lane rows, odd columns in the
+//     odd rows (any bijection of 32 lanes onto 32 consecutive columns is conflict-free for the ds_read_b64 pair: 8-byte bank slot
+//     9 * column mod 32) -- so that the horizontal 3 -> 1 pool, which needs columns 2p - 1, 2p, 2p + 1 for pooled column p, finds
+//     2p in the even row, and 2p + 1 / 2p - 1 in the partner row: one v_permlane16_swap per register PAIR + one DPP row shift;
+//   * the weight rows are permuted so that lane (column, hh = l >> 5) ends with channels 32 h + 16 hh + 0..15 in its 16 registers;
+//   * the pooled rows go to the same LDS row image ([pooled column][64 channels], 16-byte chunk XOR column & 7) from the even
+//     rows' lanes; the vertical pool and the stores are the kernel above's.
+// The sums are the same products in another order (56 MFMAs of depth 16 per output instead of 28 of depth 32): not bit-identical to
+// the 16 x 16 x 32 form; against the rounding-emulating oracle in the stage tests.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kSlots32 = 224;              // 56 sub-steps x 4 pixel tiles per conv row
+
+// slot N = (sub-step G = N >> 2, tile T = N & 3): issue the fragment of slot N + 7 into the quad slot N - 1 has consumed, wait for
+// slot N's own fragment (two reads per fragment, seven fragments behind it), issue its MFMA
+template <bool F16, int N>
+__device__ __forceinline__ void stem32_slot(f32x16 (&acc)[4], bf16x8 (&xf)[8], const bf16x8 (&wreg)[56], const uint32_t (&xa)[7], const f32x16& bias) {
+    constexpr int G = N >> 2, T = N & 3;
+    if constexpr (N + 7 < kSlots32) {
+        constexpr int M = N + 7, G2 = M >> 2, T2 = M & 3;
+        xf[M & 7] = lds_read_2xb64<32 * (G2 & 7) + 2304 * T2>(xa[G2 >> 3]);
+    }
+    constexpr int behind = kSlots32 - 1 - N < 7 ? kSlots32 - 1 - N : 7;
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * behind) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G == 0) Elem<F16>::mfma32_agpr_from(acc[T], wreg[0], xf[N & 7], bias);     // the chain starts from the bias
+    else Elem<F16>::mfma32_agpr(acc[T], wreg[G], xf[N & 7]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool F16, int... Is>
+__device__ __forceinline__ void stem32_slots(f32x16 (&acc)[4], bf16x8 (&xf)[8], const bf16x8 (&wreg)[56], const uint32_t (&xa)[7], const f32x16& bias,
+                                             std::integer_sequence<int, Is...>) {
+    (stem32_slot<F16, Is>(acc, xf, wreg, xa, bias), ...);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void conv1_pool32_kernel(const StemArgs a) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    unsigned char* const hA = smem + kRingB;                  // pooled conv row 2s   (wave row 0)
+    unsigned char* const hB = smem + kRingB + kHRowB;         // pooled conv row 2s+1 (wave row 1), two parities
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0)
+        for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0u;
+    SSTAMPK(0);
+    const int h = wave & 1, r = wave >> 1;                    // channel half, conv row within the step
+    const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
+    const int RB = a.rows_per_band;
+    const int s0 = band > 0 ? -1 : 0;
+    const int nsteps = RB / 2 - s0;
+    const int first_row = 2 * (band * RB + 2 * s0);
+    const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * (262 * kRowB) + (size_t)first_row * kRowB;
+    const int lane_src = lane * 16;
+    auto issue_row = [&](int n) {
+        const unsigned char* src = in_b + (size_t)n * kRowB;
+        unsigned char* dst = smem + (n % kRing) * kPitch;
+#pragma unroll
+        for (int p = 0; p < kRowPieces - 1; ++p) dma16(src + p * 1024 + lane_src, dst + p * 1024);
+        if (lane < (kRowB - (kRowPieces - 1) * 1024) / 16) dma16(src + (kRowPieces - 1) * 1024 + lane_src, dst + (kRowPieces - 1) * 1024);
+    };
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    const int rho = lane & 31, kc = lane >> 5;                // MFMA row of this lane's weight fragments; which 8 of a sub-step's 16 k
+    const int hh = kc;                                        // ... and, in the results, which 16 of the wave's 32 channels
+    const int lcol = 2 * (lane & 15) + ((lane >> 4) & 1);     // this lane's conv column within a 32-column tile
+    // ---- prologue: the weight matrix through LDS (one linear LDS-DMA copy, 16-byte chunk index XOR row & 15), as above
+    if (wave < 3) issue_row(wave);
+    {
+        const unsigned char* const wb = reinterpret_cast<const unsigned char*>(a.w);
+        for (int p = wave; p < kWBytes / 1024; p += 4) {
+            const int L = p * 64 + lane, row = L / 112, c = L - row * 112;
+            dma16(wb + (size_t)(row * 112 + (c ^ (row & 15))) * 16, smem + kWOff + p * 1024);
+        }
+    }
+    // accumulator register e of lane (column, hh) = channel 32 h + 16 hh + e
+    f32x16 bias_v;
+    {
+        const float4* bp = reinterpret_cast<const float4*>(a.bias + 32 * h + 16 * hh);
+        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        bias_v = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- this wave's 56 weight fragments, straight into accumulation registers: MFMA row rho is output channel
+    //      32 h + 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3) (the 32 x 32 result layout puts row (e & 3) + 8 (e >> 2) + 4 hh in register e);
+    //      sub-step g: logical 16-byte chunk 2 g + kc of that row = physical chunk 16 (g >> 3) + ((2 (g & 7) + kc) ^ (row & 15))
+    bf16x8 wreg[56];
+    {
+        const int n = 32 * h + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+        uint32_t wa[8];
+#pragma unroll
+        for (int v8 = 0; v8 < 8; ++v8) wa[v8] = smem_base + kWOff + n * 1792 + (((2 * v8 + kc) ^ (n & 15)) * 16);
+#define STEM32_WR4(G)                                                                                              \
+        asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%9\n\t"                          \
+                     "ds_read_b128 %2, %6 offset:%10\n\tds_read_b128 %3, %7 offset:%11\n\ts_waitcnt lgkmcnt(0)"    \
+                     : "=&a"(wreg[G]), "=&a"(wreg[(G) + 1]), "=&a"(wreg[(G) + 2]), "=&a"(wreg[(G) + 3])            \
+                     : "v"(wa[(G) & 7]), "v"(wa[((G) + 1) & 7]), "v"(wa[((G) + 2) & 7]), "v"(wa[((G) + 3) & 7]),   \
+                       "n"(256 * ((G) >> 3)), "n"(256 * (((G) + 1) >> 3)), "n"(256 * (((G) + 2) >> 3)), "n"(256 * (((G) + 3) >> 3)) : "memory");
+        STEM32_WR4(0) STEM32_WR4(4) STEM32_WR4(8) STEM32_WR4(12) STEM32_WR4(16) STEM32_WR4(20) STEM32_WR4(24)
+        STEM32_WR4(28) STEM32_WR4(32) STEM32_WR4(36) STEM32_WR4(40) STEM32_WR4(44) STEM32_WR4(48) STEM32_WR4(52)
+#undef STEM32_WR4
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                          // every wave has its fragments: the staging area is free
+    for (int n = 3 + wave; n < 9; n += 4) issue_row(n);       // ring rows 3..8
+    if (s0 == 0)
+        for (int i = tid; i < kHRowB / 16; i += 256) reinterpret_cast<uint4*>(hB + kHRowB)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // pixel fragment of tile T, sub-step (kernel row kr, gs): the lane's column, 16 bytes at k = 16 gs + 8 kc of the kernel row's
+    // 126 (+2) contiguous values: two ds_read_b64 (the 72-byte column pitch keeps 8-byte alignment only)
+    const uint32_t lane_off = 72 * lcol + 16 * kc;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SSTAMPK(1);
+
+    for (int st = 0; st < nsteps; ++st) {
+        SSTAMP(2);
+        const int s = s0 + st;
+        const int n0 = 4 * st;
+        if (st + 1 < nsteps) issue_row(n0 + 9 + wave);
+
+        f32x16 acc[4];
+        uint32_t xa[7];
+#pragma unroll
+        for (int kr = 0; kr < 7; ++kr) xa[kr] = smem_base + (uint32_t)(((n0 + 2 * r + kr) % kRing) * kPitch) + lane_off;
+        bf16x8 xf[8];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (counted waits below: LDS reads only may be in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        // slots 0..6: (g 0, tiles 0..3), (g 1, tiles 0..2)
+        xf[0] = lds_read_2xb64<0>(xa[0]); xf[1] = lds_read_2xb64<2304>(xa[0]); xf[2] = lds_read_2xb64<4608>(xa[0]); xf[3] = lds_read_2xb64<6912>(xa[0]);
+        xf[4] = lds_read_2xb64<32>(xa[0]); xf[5] = lds_read_2xb64<32 + 2304>(xa[0]); xf[6] = lds_read_2xb64<32 + 4608>(xa[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        stem32_slots<F16>(acc, xf, wreg, xa, bias_v, std::make_integer_sequence<int, kSlots32>{});
+        // (the wait between the last MFMA and the first VALU read of its result: nothing inside an asm is padded)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        SSTAMP(3);
+        // ---- round to the element type, ReLU on the packed pairs, horizontal 3 -> 1 max.  Pooled column 16 T + p (p = lane & 15) =
+        // max(col 2p - 1, 2p, 2p + 1) = max(O[p - 1], E[p], O[p]) with E / O = the tile's even / odd columns, which sit in the even / odd
+        // 16-lane rows.  ONE v_permlane16_swap of the packed registers k and k + 4 (channel pairs 2k.. and 2k + 8..) puts E of both
+        // into one register and O of both into the other -- rows 0 / 2 for pair k, rows 1 / 3 for pair k + 4 -- so that every lane pools
+        // (the first form swapped a register with itself: half the lanes idle, two copies per swap, 2.2 k cycles); O[p - 1] by a DPP
+        // row shift, lane 0 of a row taking O[15] of the previous tile (column -1 is padding: E[0] stands in; post-ReLU values are
+        // >= +0 and ordered like their bit patterns).  A lane ends with 8 consecutive channels of its pooled column: one 16-byte store.
+        unsigned char* const hrow = r == 0 ? hA : hB + (s & 1) * kHRowB;
+        uint32_t oprev[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            uint32_t m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t xa_ = pk_relu16(Elem<F16>::pack2(acc[T][2 * k], acc[T][2 * k + 1]));
+                const uint32_t xb_ = pk_relu16(Elem<F16>::pack2(acc[T][2 * k + 8], acc[T][2 * k + 9]));
+                const auto sw = __builtin_amdgcn_permlane16_swap(xa_, xb_, false, false);
+                const uint32_t e = sw[0], o = sw[1];                                 // E / O of pair k (rows 0, 2) and k + 4 (rows 1, 3)
+                const uint32_t wrap = T > 0 ? dpp<kDppRor1>(e, oprev[k]) : e;       // lane 0 of a row <- lane 15 of the previous tile's O
+                const uint32_t bl = dpp<kDppShr1>(wrap, o);                          // O[p - 1]; lane 0 keeps `wrap`
+                m[k] = pk_max_u16(pk_max_u16(e, o), bl);
+                oprev[k] = o;
+            }
+            const int px = 16 * T + (lane & 15);
+            const int c = 4 * h + 2 * hh + ((lane >> 4) & 1);                        // 16-byte chunk = 8 channels
+            *reinterpret_cast<uint4*>(hrow + px * 128 + ((c ^ (px & 7)) * 16)) = make_uint4(m[0], m[1], m[2], m[3]);
+        }
+        SSTAMP(4);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        SSTAMP(5);
+        __syncthreads();
+        SSTAMP(6);
+        if (s >= 0) {
+            const int px = tid >> 2, q = tid & 3;
+            const int prow = band * (RB / 2) + s;
+            uint16_t* const orow = a.out + (size_t)b * (66 * 66 * 64) + (size_t)(prow + 1) * (66 * 64) + (size_t)(px + 1) * 64;
+            const unsigned char* const carry = hB + ((s + 1) & 1) * kHRowB;
+            const unsigned char* const cur1 = hB + (s & 1) * kHRowB;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int c = 2 * q + c2;
+                const int off = px * 128 + (((2 * c) ^ (2 * (px & 7))) * 8);
+                const uint4 va = *reinterpret_cast<const uint4*>(hA + off);
+                const uint4 vb = *reinterpret_cast<const uint4*>(cur1 + off);
+                const uint4 vc = *reinterpret_cast<const uint4*>(carry + off);
+                auto mx = [](uint32_t x, uint32_t y, uint32_t z) -> uint32_t { return pk_max_u16(pk_max_u16(x, y), z); };
+                *reinterpret_cast<uint4*>(orow + c * 8) = make_uint4(mx(va.x, vb.x, vc.x), mx(va.y, vb.y, vc.y), mx(va.z, vb.z, vc.z), mx(va.w, vb.w, vc.w));
+            }
+        }
+        SSTAMP(7);
+        __syncthreads();
+        SSTAMP(8);
+    }
+    SSTAMPK(9);
+}
+
 }  // namespace
 
 namespace spsp {
 
 // conv1 + BN + ReLU + max-pool for B crops: in = native [B][262][264][18], out = [B][66][66][64] (interior).
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band) {
+                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band, bool mfma32) {
     SPSP_REQUIRE(in && w && bias && out && B > 0, "conv_stem: bad arguments");
     SPSP_REQUIRE(rows_per_band == 0 || (rows_per_band >= 4 && rows_per_band <= 128 && (rows_per_band & (rows_per_band - 1)) == 0),
                  "conv_stem: bands of %d conv rows (a power of two, 4 .. 128)", rows_per_band);
@@ -387,6 +589,8 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
     a.bands = 128 / a.rows_per_band;
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<false>>(kLds));
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<true>>(kLds));
+    SPSP_TRY(ensure_dynamic_lds<&conv1_pool32_kernel<false>>(kLds));
+    SPSP_TRY(ensure_dynamic_lds<&conv1_pool32_kernel<true>>(kLds));
     a.dbg = nullptr;
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
@@ -394,20 +598,24 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
         const int diag = getenv("SPSP_STEM_DIAG") ? atoi(getenv("SPSP_STEM_DIAG")) : 0;
         (void)ensure_dynamic_lds<&conv1_pool_kernel<true, 1>>(kLds);
         (void)ensure_dynamic_lds<&conv1_pool_kernel<true, 2>>(kLds);
-        if (diag == 1) conv1_pool_kernel<true, 1><<<dim3(B * a.bands), 256, kLds, st>>>(a);
+        if (mfma32 && diag == 0) { if (f16) conv1_pool32_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a); else conv1_pool32_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a); }
+        else if (diag == 1) conv1_pool_kernel<true, 1><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         else if (diag == 2) conv1_pool_kernel<true, 2><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         else if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         else conv1_pool_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         (void)hipDeviceSynchronize();
         unsigned long long hh[16];
         (void)hipMemcpy(hh, a.dbg, sizeof hh, hipMemcpyDeviceToHost);
-        fprintf(stderr, "stem[diag %d] wg9 (band 1, 9 steps): prologue %llu | step3: K loop %llu | h-pool + LDS writes %llu | vmcnt/lgkm wait %llu | barrier %llu | vertical + stores %llu | barrier %llu | whole kernel %llu cycles\n",
-                diag, hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
+        fprintf(stderr, "stem[%s diag %d] wg9 (band 1, 9 steps): prologue %llu | step3: K loop %llu | h-pool + LDS writes %llu | vmcnt/lgkm wait %llu | barrier %llu | vertical + stores %llu | barrier %llu | whole kernel %llu cycles\n",
+                mfma32 ? "32x32x16" : "16x16x32", diag, hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
         (void)hipFree(a.dbg);
         return SPSP_OK;
     }
 #endif
-    if (f16) launch_kernel(&conv1_pool_kernel<true, 0>, dim3(B * a.bands), dim3(256), kLds, st, a);
+    if (mfma32) {
+        if (f16) launch_kernel(&conv1_pool32_kernel<true>, dim3(B * a.bands), dim3(256), kLds, st, a);
+        else launch_kernel(&conv1_pool32_kernel<false>, dim3(B * a.bands), dim3(256), kLds, st, a);
+    } else if (f16) launch_kernel(&conv1_pool_kernel<true, 0>, dim3(B * a.bands), dim3(256), kLds, st, a);
     else launch_kernel(&conv1_pool_kernel<false, 0>, dim3(B * a.bands), dim3(256), kLds, st, a);
     SPSP_HIP_CHECK(hipGetLastError());
     return SPSP_OK;

@@ -292,7 +292,12 @@ struct spsp_regressor {
     int f16;               // 0: bf16 storage + bf16 MFMA (precision 0), 1: fp16 storage + f16 MFMA (precision 1)
     uint16_t* w[SPSP_NUM_CONVS];
     float* bias[SPSP_NUM_CONVS];
+    uint16_t* wrs[3] = {nullptr, nullptr, nullptr};   // layer2's three 3x3 / 1 convs (6, 8, 9) as register-order fragments (conv_rs.hip)
+    int rs_wgs = 0;        // layer2's 3x3 / 1 convs on conv_rs.hip with this many workgroups (plan "throughput": 64); 0: conv_p4.hip
+    uint16_t* wq2 = nullptr; // layer2.0's 3x3 / 2 + 1x1 / 2 pair as register-order MFMA fragments (conv_s2q.hip)
+    bool use_s2q = true;   // layer2.0 on conv_s2q.hip (all 128 output channels per workgroup); off: conv_s2rs.hip (SPSP_DEBUG_PLAN_S2Q)
     uint16_t* wfb[2];      // layer1's two BasicBlocks: both convolutions' weights as register-order MFMA fragments (conv_fb.hip)
+    bool stem32 = true;    // the stem on v_mfma_f32_32x32x16 (conv1_pool32_kernel); off: the 16x16x32 form (SPSP_DEBUG_PLAN_STEM32)
     bool use_fb = true;    // layer1: one launch per BasicBlock (conv_fb.hip); off: two conv_wres launches per block (SPSP_DEBUG_PLAN_FB)
     float *w1f, *w13, *w2, *w3;   // IEF weights in the fused kernel's form (see ief_fused_kernel)
     float *cvec, *b2, *p0;
@@ -375,6 +380,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
         ProfScope ps(ctx, kKConvWres, st, true);
         return launch_conv_wres(a, r->wres_cu_div >= 32 ? r->wres_cu_div : ctx->num_cus / r->wres_cu_div, st);      // (>= 32: an explicit workgroup count, experiments)
     }
+    if (L == 1 && r->rs_wgs >= 2 && (ci == 6 || ci == 8 || ci == 9) && conv_patch_supported(a) && a.Wo == 32 && a.N == 128 && !pool_out) {
+        ProfScope ps(ctx, kKConvRs, st, true);          // plan "throughput": a channel block's weights in registers, persistent workgroups
+        return launch_conv_rs(a.in, r->wrs[ci == 6 ? 0 : ci - 7], a.bias, a.res, a.out, B, r->f16, a.relu, r->rs_wgs, st);
+    }
     if (conv_patch_supported(a)) {                     // 3x3 / 1 of layer2-4 at whole multiples of 128 pixels
         if (((r->p4_layers >> L) & 1) && conv_p4_supported(a)) {       // layer2; layer3 in plan "throughput": no K split, producer waves
             ProfScope ps(ctx, kKConvP4, st, true);
@@ -388,6 +397,10 @@ int run_conv(spsp_ctx* ctx, spsp_regressor* r, int ci, const uint16_t* in, int S
     }
     // stride-2 3x3, 1x1 downsample, and every conv of a batch that does not fill whole patch tiles: LDS-DMA ring kernel
     if (ci2 >= 0) { a.w2 = r->w[ci2]; a.bias2 = r->bias[ci2]; a.out2 = out2; a.n2 = kConvs[ci2].cout; }
+    if (r->use_s2 && r->use_s2q && r->wq2 && conv_s2rs_supported(a) && a.N == 128 && a.n2 == 128) {      // layer2.0, all channels per workgroup
+        ProfScope ps(ctx, kKConvS2q, st, true);
+        return launch_conv_s2q(a.in, r->wq2, a.bias, a.bias2, a.out, a.out2, B, r->f16, a.relu, ctx->num_cus / r->s2rs_cu_div, st);
+    }
     if (r->use_s2 && r->use_s2rs && conv_s2rs_supported(a)) {   // layer2.0: the same planes, weights stationary in registers
         ProfScope ps(ctx, kKConvS2, st, true);
         return launch_conv_s2rs(a, ctx->num_cus / r->s2rs_cu_div, st);
@@ -453,6 +466,20 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         }
         TRY(r->pool.upload(&r->w[ci], wt.data(), wt.size()));
         TRY(r->pool.upload(&r->bias[ci], bias.data(), bias.size()));
+        if (ci == 6 || ci == 8 || ci == 9) {           // layer2's 3x3 / 1 convs for conv_rs.hip
+            std::vector<uint16_t> frag;
+            pack_rs_fragments(wt.data(), frag);
+            TRY(r->pool.upload(&r->wrs[ci == 6 ? 0 : ci - 7], frag.data(), frag.size()));
+        }
+        if (ci == 5 || ci == 7) {                      // layer2.0: the 3x3 / 2 conv (5) and its downsample (7) for conv_s2q.hip
+            static thread_local std::vector<uint16_t> main3x3;
+            if (ci == 5) main3x3 = wt;
+            else {
+                std::vector<uint16_t> frag;
+                pack_s2q_fragments(main3x3.data(), wt.data(), frag);
+                TRY(r->pool.upload(&r->wq2, frag.data(), frag.size()));
+            }
+        }
         if (ci >= 1 && ci <= 4) {                      // layer1: convs 1, 2 = block 0; 3, 4 = block 1
             static thread_local std::vector<uint16_t> first;
             if (ci & 1) first = wt;
@@ -615,7 +642,7 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
     // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
     {
         ProfScope ps(ctx, kKStem, st, true);
-        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st, r->stem_band));
+        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st, r->stem_band, r->stem32));
     }
     r->stage_ptr[0] = nullptr;
     r->stage_ptr[1] = r->p1;
@@ -742,6 +769,7 @@ int spsp_regressor_set_plan(spsp_regressor* r, int plan) {
     r->wres_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 4;
     r->stem_band = plan == SPSP_PLAN_LATENCY ? 0 : 32;      // (bands of 32 and of 64 rows tie or 32 wins by 1-1.5 %: profiles/r04_ab_narrow.txt)
     r->s2rs_cu_div = plan == SPSP_PLAN_LATENCY ? 1 : 2;      // layer2.0: four tiles per resident weight set (128 workgroups at B = 32)
+    r->rs_wgs = plan == SPSP_PLAN_LATENCY ? 0 : 64;          // layer2's 3x3 / 1 convs on conv_rs.hip: eight tiles per resident weight set
     return SPSP_OK;
 }
 
@@ -753,7 +781,13 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             SPSP_REQUIRE(value == 16 || value == 32, "spsp_regressor_debug: IEF blocks of %d players (16 or 32)", value);
             r->ief_block = value;
             return SPSP_OK;
+        case SPSP_DEBUG_PLAN_RS:
+            SPSP_REQUIRE(value == 0 || (value >= 2 && value <= 512 && value % 2 == 0), "spsp_regressor_debug: conv_rs on %d workgroups (0: off; even)", value);
+            r->rs_wgs = value;
+            return SPSP_OK;
         case SPSP_DEBUG_PLAN_FB: r->use_fb = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_STEM32: r->stem32 = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_S2Q: r->use_s2q = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_P4: r->p4_layers = value & 6; return SPSP_OK;      // layer2 (bit 1), layer3 (bit 2)

@@ -331,6 +331,7 @@ def test_layer2_stride2_pair_with_register_stationary_weights_is_bit_identical(d
             x, _ = S.proxy_crops(B, seed=60 + B)
             native = reg.pack(torch.from_numpy(x).to(dev))
             got = []
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2Q, 0), 'debug')      # (round 5's conv_s2q.hip off: below)
             for rs, cus in ((0, 1), (1, 1), (1, 2), (1, 4)):      # (cus: 4 and 8 tiles per workgroup where they divide -- plan "throughput")
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2RS, rs), 'debug')
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2RS_CUS, cus), 'debug')
@@ -342,6 +343,81 @@ def test_layer2_stride2_pair_with_register_stationary_weights_is_bit_identical(d
             for other in got[1:]:
                 for a, b in zip(got[0], other):
                     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_layer2_stride2_pair_with_all_channels_in_one_workgroup_matches_the_channel_block_kernel(dev):
+    """csrc/conv_s2q.hip (round 5, the default): layer2.0's 3x3 / 2 convolution + 1x1 / 2 downsample with all 128 output channels in
+    one workgroup -- the parity planes staged once, a wave = a 32-channel quarter over the whole K, weights in registers, tiles of
+    4 x 16 pixels -- against conv_s2rs.hip (`SPSP_DEBUG_PLAN_S2Q` = 0: 64-channel blocks, K halves added through LDS).  The same
+    products added in another order (taps 0..8 in a row instead of plane by plane, no split of K): layer2's OUTPUT map -- three more
+    convolutions behind the pair -- within one unit in the last place of the element type at its largest value (f16: 2^-10 = 1e-3 of
+    it, measured exactly that: 0.00195 at 2.86; bf16: 2^-7), the regressor outputs within 1e-4 / 5e-4 (measured 3.0e-5); against the rounding-emulating
+    oracle in the stage tests, which run it.  Two, four and eight tiles per workgroup (the grids of
+    both plans) are the same bits."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec, batches in (('f16', (32, 22, 3, 1)), ('bf16', (32, 5))):
+        for B in batches:
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=90 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = {}
+            for s2q, cus in ((0, 1), (1, 1), (1, 2), (1, 4)):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2Q, s2q), 'debug')
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2RS_CUS, cus), 'debug')
+                out = [t.clone() for t in reg(native)] + [reg.read_stage(3, B).clone()]
+                torch.cuda.synchronize()
+                reg.check_status()
+                got[(s2q, cus)] = out
+            for cus in (2, 4):
+                assert all(torch.equal(a, b) for a, b in zip(got[(1, 1)], got[(1, cus)])), (prec, B, cus)
+            ref, new = got[(0, 1)], got[(1, 1)]
+            assert all(torch.isfinite(t).all() for t in new)
+            scale = ref[3].abs().max().item()
+            assert (new[3] - ref[3]).abs().max().item() <= (1e-3 if prec == 'f16' else 8e-3) * scale, (prec, B)
+            assert max((a - b).abs().max().item() for a, b in zip(new[:3], ref[:3])) <= (1e-4 if prec == 'f16' else 5e-4), (prec, B)
+
+
+def test_layer2_with_register_stationary_weights_matches_the_streaming_kernel(dev):
+    """csrc/conv_rs.hip (round 5, plan "throughput"): layer2's three 3x3 / 1 convolutions with a 64-channel block's weights stationary
+    in registers and persistent workgroups over 8 x 16-pixel tiles (`SPSP_DEBUG_PLAN_RS` = workgroups; 0 = conv_p4.hip, which streams
+    the weight slabs through an LDS ring per tile).  The same products added in another order (K-step = 4 tap + 2 chunk + half instead
+    of chunk-major): layer2's map within one unit in the last place of the element type at its largest value, the regressor outputs
+    within 1e-4 / 5e-4; B = 32, 22 (176 tiles over 32 ranges: ragged), 3 and 1; 64, 32, 128 and 256 workgroups give the same bits.
+    conv_p4.hip itself is held to the rounding-emulating oracle in the stage tests."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec, batches in (('f16', (32, 22, 3, 1)), ('bf16', (32, 5))):
+        for B in batches:
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=130 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = {}
+            for wgs in (0, 64, 32, 128, 256):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_RS, wgs), 'debug')
+                out = [t.clone() for t in reg(native)] + [reg.read_stage(3, B).clone()]
+                torch.cuda.synchronize()
+                reg.check_status()
+                got[wgs] = out
+            for wgs in (32, 128, 256):
+                assert all(torch.equal(a, b) for a, b in zip(got[64], got[wgs])), (prec, B, wgs)
+            ref, new = got[0], got[64]
+            assert all(torch.isfinite(t).all() for t in new)
+            scale = ref[3].abs().max().item()
+            assert (new[3] - ref[3]).abs().max().item() <= (1e-3 if prec == 'f16' else 8e-3) * scale, (prec, B, (new[3] - ref[3]).abs().max().item(), scale)
+            assert max((a - b).abs().max().item() for a, b in zip(new[:3], ref[:3])) <= (1e-4 if prec == 'f16' else 5e-4), (prec, B)
+    # the plans select it: "throughput" runs conv_rs (64 workgroups), "latency" conv_p4
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=32, precision='f16').load_state_dict(sd).to(dev)
+    x, _ = S.proxy_crops(32, seed=131)
+    native = reg.pack(torch.from_numpy(x).to(dev))
+    thr = [t.clone() for t in reg.set_plan('throughput')(native)]
+    lat = [t.clone() for t in reg.set_plan('latency')(native)]
+    torch.cuda.synchronize()
+    assert all(float((a - b).abs().max()) <= 1e-4 for a, b in zip(lat, thr))
 
 
 def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
@@ -376,6 +452,40 @@ def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
                     assert float((a - b).abs().max()) <= tol_map * float(b.abs().max())
             # plan 2 leaves layer3 on conv_patch.hip: given the same layer2 map, plan 6's layer2 map is plan 2's bit for bit
             assert torch.equal(got[2][1][0], got[6][1][0])
+
+
+def test_stem_on_32x32x16_mfma_matches_the_16x16x32_form(dev):
+    """csrc/conv_stem.hip, conv1_pool32_kernel (round 5, the default): conv1 + BN + ReLU + max-pool on v_mfma_f32_32x32x16 -- one MFMA per
+    32 cycles for a loop that is bound by its issue slots, even / odd conv columns in even / odd 16-lane rows, the horizontal pool by
+    v_permlane16_swap + a DPP row shift -- against the 16x16x32 kernel of rounds 1-4 (`SPSP_DEBUG_PLAN_STEM32` = 0).  The same products
+    summed in another order (56 MFMAs of depth 16 per output instead of 28 of depth 32): the pooled map within one unit in the last
+    place of the element type at its largest value, the regressor outputs within 1e-4 / 5e-4; B = 32, 22 (16-row bands), 3 and 1
+    (finer bands), the band heights of plan "throughput", both element types.  Against the rounding-emulating oracle in the stage
+    tests, which run it."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    for prec, batches in (('f16', (32, 22, 3, 1)), ('bf16', (32, 5))):
+        for B in batches:
+            reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision=prec).load_state_dict(sd).to(dev)
+            r = rt.get(dev)
+            x, _ = S.proxy_crops(B, seed=110 + B)
+            native = reg.pack(torch.from_numpy(x).to(dev))
+            got = {}
+            for m32, band in ((0, 0), (1, 0), (1, 32), (1, 64)):
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM32, m32), 'debug')
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM_BAND, band), 'debug')
+                out = [t.clone() for t in reg(native)] + [reg.read_stage(1, B).clone()]
+                torch.cuda.synchronize()
+                reg.check_status()
+                got[(m32, band)] = out
+            for band in (32, 64):            # which workgroup computes a row changes, nothing about the row
+                assert all(torch.equal(a, b) for a, b in zip(got[(1, 0)], got[(1, band)])), (prec, B, band)
+            ref, new = got[(0, 0)], got[(1, 0)]
+            assert all(torch.isfinite(t).all() for t in new)
+            scale = ref[3].abs().max().item()
+            assert (new[3] - ref[3]).abs().max().item() <= (1e-3 if prec == 'f16' else 8e-3) * scale, (prec, B, (new[3] - ref[3]).abs().max().item(), scale)
+            assert max((a - b).abs().max().item() for a, b in zip(new[:3], ref[:3])) <= (1e-4 if prec == 'f16' else 5e-4), (prec, B)
 
 
 def test_layer1_basic_block_in_one_launch_is_bit_identical_to_two_launches(dev):
@@ -414,7 +524,8 @@ def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
     `SPSP_DEBUG_PLAN_STEM_BAND`, `SPSP_DEBUG_PLAN_P4_CUS`).  Which workgroup computes a tile changes, nothing about the tile: the pooled stem map, layer1's
     map, layer2's / layer3's maps and the regressor outputs are equal bit for bit at B = 32 (64-row bands), 22 (32-row bands; 176
     conv_p4 tiles on 64 / 32 workgroups: uneven tile counts) and 3, both element types;
-    and the two named plans differ only by layer3's summation order (conv_p4.hip against conv_patch.hip)."""
+    and the two named plans differ only by layer2's (conv_rs.hip against conv_p4.hip, round 5) and layer3's (conv_p4.hip against
+    conv_patch.hip) summation order: the map in front of layer2 is equal bit for bit."""
     from soccerplayershapepose_amd import runtime as rt
     from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
     sd = S.regressor_state_dict(seed=0)
@@ -426,6 +537,7 @@ def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
             native = reg.pack(torch.from_numpy(x).to(dev))
             got = []
             r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_P4, 6), 'debug')
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_RS, 0), 'debug')
             for div, band, p4div in ((1, 0, 1), (4, 64, 4), (2, 32, 2), (16, 16, 8)):
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_WRES_CUS, div), 'debug')
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM_BAND, band), 'debug')
@@ -438,10 +550,10 @@ def test_narrow_persistent_grids_of_plan_throughput_are_bit_identical(dev):
                 for a, b in zip(got[0], other):
                     assert torch.isfinite(a).all() and torch.equal(a, b)
             if B == 32:
-                lat = [t.clone() for t in reg.set_plan('latency')(native)] + [reg.read_stage(3, B).clone()]
-                thr = [t.clone() for t in reg.set_plan('throughput')(native)] + [reg.read_stage(3, B).clone()]
+                lat = [t.clone() for t in reg.set_plan('latency')(native)] + [reg.read_stage(2, B).clone()]
+                thr = [t.clone() for t in reg.set_plan('throughput')(native)] + [reg.read_stage(2, B).clone()]
                 torch.cuda.synchronize()
-                assert torch.equal(lat[-1], thr[-1])                      # up to layer2 the plans run the same arithmetic
+                assert torch.equal(lat[-1], thr[-1])                      # up to layer1 the plans run the same arithmetic
                 assert all(float((a - b).abs().max()) <= (1e-4 if prec == 'f16' else 1e-3) for a, b in zip(lat[:-1], thr[:-1]))
 
 
@@ -922,18 +1034,23 @@ def test_single_view_fit_warm_started_from_its_own_record_continues_the_trajecto
 
 
 # ---------------------------------------------------------------- regressor (a2-a4)
+_STAGE_ORACLE = {}
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'f16'])
 # 3: an odd batch: layer4 (tiles = pairs of 8 x 8 images) runs on B + 1 crops, the extra one never read; 6: layer4 in whole 128-pixel tiles (two 8 x 8 images each) that are no whole
 # 256-pixel ones, as for the 22-player frame, and the stem's band height by cost; 8: every patch kernel incl. the 8x8 one; 32: the
 # BENCHMARK plan (all 32 crops checked); '32-contended': the same while a second regressor keeps the chip busy from another stream,
 # so the persistent / dynamically scheduled kernels are checked against the oracle under CU contention, not only against themselves
-@pytest.mark.parametrize('B', [3, 6, 8, 32, '32-contended'])
+# '32-throughput': the launch plan PlayerPipeline runs (narrow persistent grids; layer2 on conv_rs.hip, layer3 on conv_p4.hip)
+@pytest.mark.parametrize('B', [3, 6, 8, 32, '32-contended', '32-throughput'])
 def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_gpu_f16, regressor_sd_np, dev, B, precision):
     """Every stage of the backbone against the oracle rounding weights and stored activations to the SAME element
     type at the same points (bf16: precision 0; fp16: precision 1)."""
     from oracle import regressor as OR
     contended = B == '32-contended'
-    B = 32 if contended else B
+    throughput = B == '32-throughput'
+    B = 32 if contended or throughput else B
     x, _ = S.proxy_crops(B, seed=4)
     regressor_gpu = regressor_gpu_f16 if precision == 'f16' else regressor_gpu
     ulp = 1.0 if precision == 'bf16' else 0.125          # fp16 has 3 more mantissa bits
@@ -948,13 +1065,21 @@ def test_backbone_stages_against_bf16_emulating_oracle(regressor_gpu, regressor_
         with torch.cuda.stream(side):
             for _ in range(6):
                 other(native_o)
-    cam, pose, shape, feats = regressor_gpu(xt, return_feats=True)
+    if throughput:
+        regressor_gpu.set_plan('throughput')
+    try:
+        cam, pose, shape, feats = regressor_gpu(xt, return_feats=True)
+        torch.cuda.synchronize()
+    finally:
+        regressor_gpu.set_plan('latency')                 # the fixture is shared: back to a handle's default
     if contended:
         with torch.cuda.stream(side):
             for _ in range(2):
                 other(native_o)
         torch.cuda.synchronize()
-    f_emu, stages = OR.encoder_forward(regressor_sd_np, x, emulate_bf16=precision, return_stages=True)
+    if (B, precision) not in _STAGE_ORACLE:                # the three B = 32 cases share one CPU pass of the oracle
+        _STAGE_ORACLE[(B, precision)] = OR.encoder_forward(regressor_sd_np, x, emulate_bf16=precision, return_stages=True)
+    f_emu, stages = _STAGE_ORACLE[(B, precision)]
     # stage 0 (the 128 x 128 x 64 map after conv1 + ReLU) does not exist on the GPU: the stem kernel pools in registers
     names = ['conv1', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4']
     with pytest.raises(ValueError):

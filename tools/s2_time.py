@@ -1,0 +1,44 @@
+"""The three stride-2 launches of the regressor's forward, one batch in flight: per-launch durations (the kernels' own timestamps) with
+layer2.0 on conv_s2q.hip (round 5: all 128 output channels per workgroup) and on conv_s2rs.hip (round 4: 64-channel blocks), in both plans.
+usage: python tools/s2_time.py [reps]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from soccerplayershapepose_amd import _abi, synthetic as S  # noqa: E402
+from soccerplayershapepose_amd import runtime as rt  # noqa: E402
+from soccerplayershapepose_amd.models.regressor import SingleInputRegressor  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device('cuda', 0)
+r = rt.get(dev)
+nk = r.lib.spsp_profile_num_kernels()
+names = [r.lib.spsp_profile_kernel_name(i).decode() for i in range(nk)]
+sd = S.regressor_state_dict(seed=0)
+for B in (32, 22):
+    reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(sd).to(dev)
+    x, _ = S.proxy_crops(B, seed=3)
+    native = reg.pack(torch.from_numpy(x).to(dev))
+    for rnd in range(2):
+        for plan in ('latency', 'throughput'):
+            for s2q in (0, 1):
+                reg.set_plan(plan)
+                r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_S2Q, s2q), 'debug')
+                reg(native)
+                torch.cuda.synchronize()
+                ms, cnt = (C.c_double * nk)(), (C.c_int * nk)()
+                r.check(r.lib.spsp_profile_select(r.ctx, -1), 'select')
+                r.check(r.lib.spsp_profile_enable(r.ctx, 1), 'enable')
+                for _ in range(reps):
+                    reg(native)
+                    torch.cuda.synchronize()
+                r.check(r.lib.spsp_profile_enable(r.ctx, 0), 'enable')
+                r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'read')
+                tot = sum(ms[i] for i in range(nk) if cnt[i] and names[i].startswith('conv')) * 1e3 / reps
+                parts = ', '.join(f'{k} {cnt[names.index(k)] // reps} x {1e3 * ms[names.index(k)] / cnt[names.index(k)]:.2f} us'
+                                  for k in ('conv3x3s2q_kernel', 'conv3x3s2_kernel') if cnt[names.index(k)])
+                print(f'B={B} plan {plan:10s} s2q={s2q}: {parts}; all convolutions {tot:6.1f} us', flush=True)
