@@ -46,6 +46,7 @@ def to_library_name(rocprof_name, names):
     (element type / buffering flags follow).  A rocprof kernel belongs to the library name with the same base and the
     longest matching argument prefix."""
     base, args = split_template(short(rocprof_name))
+    base = re.sub(r'^conv1_pool32r?_kernel$', 'conv1_pool_kernel', base)          # the stem's forms are one table row
     best = None
     for n in names:
         nb, na = split_template(n)

@@ -386,8 +386,10 @@ __device__ __forceinline__ void stem32_slot(f32x16 (&acc)[4], bf16x8 (&xf)[8], c
         constexpr int M = N + 7, G2 = M >> 2, T2 = M & 3;
         xf[M & 7] = lds_read_2xb64<32 * (G2 & 7) + 2304 * T2>(xa[G2 >> 3]);
     }
+    // a lone wave issues an instruction every ~8 cycles whatever its kind, so a slot of two reads, a wait and an MFMA is 32 cycles of
+    // issue for 32 cycles of matrix pipe: ONE wait per two slots (for both slots' fragments: six fragments stay in flight) makes room
     constexpr int behind = kSlots32 - 1 - N < 7 ? kSlots32 - 1 - N : 7;
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * behind) : "memory");
+    if constexpr ((N & 1) == 0 || behind < 7) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(behind > 0 ? 2 * (behind - 1) : 0) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G == 0) Elem<F16>::mfma32_agpr_from(acc[T], wreg[0], xf[N & 7], bias);     // the chain starts from the bias
     else Elem<F16>::mfma32_agpr(acc[T], wreg[G], xf[N & 7]);
@@ -558,13 +560,265 @@ __global__ __launch_bounds__(256, 1) void conv1_pool32_kernel(const StemArgs a) 
     SSTAMPK(9);
 }
 
+
+// ==== round 5, second form: the pooling RIDES in the K loop ======================================================================
+// conv1_pool32_kernel spends 1.9 k of a step's 10 k cycles outside the MFMAs (stamps: K loop 8.2 k | horizontal pool 0.95 k | LDS wait
+// 0.34 k | barrier | vertical pool + stores 0.4 k | barrier).  A 32 x 32 x 16 MFMA occupies the matrix pipe for 32 cycles and the
+// wave's issue for 8, so -- unlike the 16 x 16 x 32 loop, where round 4 measured this zero-sum -- other instructions fit beside it.
+// What makes it possible without a second accumulator set:
+//   * the four pixel tiles run as two PAIRS (tiles 0, 1 over all 56 sub-steps in slots 0..111, then tiles 2, 3): pair A's sums are
+//     final at slot 112 and not needed before the next step's slot 0, pair B's from the step's end to the next step's slot 112; two
+//     chains interleaved keep dependent MFMAs 64 cycles apart;
+//   * step s' K loop carries: H_B(s - 1) -- the horizontal pool of pair B of the previous step -- in slots 2..44, H_A(s) in slots
+//     118..160, V_lo(s - 1) -- the vertical max and the store of pooled columns 0..31 -- at slots 52 / 64 and V_hi(s - 2) (columns
+//     32..63) at slots 70 / 82: every LDS hand-off (H writes -> V reads) then crosses exactly ONE barrier, the step's own (which
+//     also publishes the input ring rows), with the pooled-row buffers two deep by step parity; the row above (conv row 2 s' - 1),
+//     which the first form kept in a third LDS row, is carried in registers: it is what the same thread read one step before;
+//   * the extra LDS instructions are inline asm like the fragment reads: LDS returns in order, so the slots' counted lgkmcnt waits
+//     (at most 14 outstanding) cover anything issued eight slots earlier; an extra instruction inside the window only makes a wait
+//     stricter.  hipcc never sees an LDS access here and adds no wait of its own.
+// Same products in the same order per output as conv1_pool32_kernel: bit-identical (test_stem_...).
+constexpr int kLds32r = kRingB + 4 * kHRowB;                  // hA[2], hB[2] by step parity: 156 320 B
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N> struct Slot32r {                             // slot N -> (sub-step G, tile T), pair-major
+    static constexpr int P = N / 112, J = N % 112, G = J >> 1, T = 2 * P + (J & 1);
+};
+
+template <bool F16, int N, typename Ride>
+__device__ __forceinline__ void stem32r_slot(f32x16 (&acc)[4], bf16x8 (&xf)[8], const bf16x8 (&wreg)[56], const uint32_t (&xa)[7], const f32x16& bias, Ride& ride) {
+    constexpr int G = Slot32r<N>::G, T = Slot32r<N>::T;
+    if constexpr (N + 7 < kSlots32) {
+        constexpr int M = N + 7, G2 = Slot32r<M>::G, T2 = Slot32r<M>::T;
+        // (two ds_read_b64: as ONE ds_read2_b64 per fragment -- an address register per (kernel row, tile), the sub-step in the 8-bit
+        // offsets -- the K loop took 15.1 k cycles instead of 8.8 k: the pair is served as two conflicting passes)
+        xf[M & 7] = lds_read_2xb64<32 * (G2 & 7) + 2304 * T2>(xa[G2 >> 3]);
+    }
+    constexpr int behind = kSlots32 - 1 - N < 7 ? kSlots32 - 1 - N : 7;                      // (one wait per two slots: conv1_pool32_kernel)
+    if constexpr ((N & 1) == 0 || behind < 7) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(behind > 0 ? 2 * (behind - 1) : 0) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G == 0) Elem<F16>::mfma32_agpr_from(acc[T], wreg[0], xf[N & 7], bias);
+    else Elem<F16>::mfma32_agpr(acc[T], wreg[G], xf[N & 7]);
+    __builtin_amdgcn_sched_barrier(0);
+    ride(std::integral_constant<int, N>{});
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool F16, typename Ride, int... Is>
+__device__ __forceinline__ void stem32r_slots(f32x16 (&acc)[4], bf16x8 (&xf)[8], const bf16x8 (&wreg)[56], const uint32_t (&xa)[7], const f32x16& bias, Ride& ride,
+                                              std::integer_sequence<int, Is...>) {
+    (stem32r_slot<F16, Is>(acc, xf, wreg, xa, bias, ride), ...);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256, 1) void conv1_pool32r_kernel(const StemArgs a) {
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0)
+        for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0u;
+    SSTAMPK(0);
+    const int h = wave & 1, r = wave >> 1;
+    const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
+    const int RB = a.rows_per_band;
+    const int s0 = band > 0 ? -1 : 0;
+    const int nsteps = RB / 2 - s0;
+    const int first_row = 2 * (band * RB + 2 * s0);
+    const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * (262 * kRowB) + (size_t)first_row * kRowB;
+    const int lane_src = lane * 16;
+    auto issue_row = [&](int n) {
+        const unsigned char* src = in_b + (size_t)n * kRowB;
+        unsigned char* dst = smem + (n % kRing) * kPitch;
+#pragma unroll
+        for (int p = 0; p < kRowPieces - 1; ++p) dma16(src + p * 1024 + lane_src, dst + p * 1024);
+        if (lane < (kRowB - (kRowPieces - 1) * 1024) / 16) dma16(src + (kRowPieces - 1) * 1024 + lane_src, dst + (kRowPieces - 1) * 1024);
+    };
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    const int rho = lane & 31, kc = lane >> 5;
+    const int hh = kc;
+    const int lcol = 2 * (lane & 15) + ((lane >> 4) & 1);
+    // ---- prologue: conv1_pool32_kernel's
+    if (wave < 3) issue_row(wave);
+    {
+        const unsigned char* const wb = reinterpret_cast<const unsigned char*>(a.w);
+        for (int p = wave; p < kWBytes / 1024; p += 4) {
+            const int L = p * 64 + lane, row = L / 112, c = L - row * 112;
+            dma16(wb + (size_t)(row * 112 + (c ^ (row & 15))) * 16, smem + kWOff + p * 1024);
+        }
+    }
+    f32x16 bias_v;
+    {
+        const float4* bp = reinterpret_cast<const float4*>(a.bias + 32 * h + 16 * hh);
+        const float4 b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+        bias_v = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 wreg[56];
+    {
+        const int n = 32 * h + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+        uint32_t wa[8];
+#pragma unroll
+        for (int v8 = 0; v8 < 8; ++v8) wa[v8] = smem_base + kWOff + n * 1792 + (((2 * v8 + kc) ^ (n & 15)) * 16);
+#define STEM32_WR4(G)                                                                                              \
+        asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%9\n\t"                          \
+                     "ds_read_b128 %2, %6 offset:%10\n\tds_read_b128 %3, %7 offset:%11\n\ts_waitcnt lgkmcnt(0)"    \
+                     : "=&a"(wreg[G]), "=&a"(wreg[(G) + 1]), "=&a"(wreg[(G) + 2]), "=&a"(wreg[(G) + 3])            \
+                     : "v"(wa[(G) & 7]), "v"(wa[((G) + 1) & 7]), "v"(wa[((G) + 2) & 7]), "v"(wa[((G) + 3) & 7]),   \
+                       "n"(256 * ((G) >> 3)), "n"(256 * (((G) + 1) >> 3)), "n"(256 * (((G) + 2) >> 3)), "n"(256 * (((G) + 3) >> 3)) : "memory");
+        STEM32_WR4(0) STEM32_WR4(4) STEM32_WR4(8) STEM32_WR4(12) STEM32_WR4(16) STEM32_WR4(20) STEM32_WR4(24)
+        STEM32_WR4(28) STEM32_WR4(32) STEM32_WR4(36) STEM32_WR4(40) STEM32_WR4(44) STEM32_WR4(48) STEM32_WR4(52)
+#undef STEM32_WR4
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    for (int n = 3 + wave; n < 9; n += 4) issue_row(n);
+    const uint32_t lane_off = 72 * lcol + 16 * kc;
+
+    // ---- what rides.  Pooled rows in LDS: row image [64 pooled columns][64 channels], 16-byte chunk c of column px at px * 128 +
+    //      ((c ^ (px & 7)) * 16); hA[parity] at kRingB + parity * kHRowB (conv row 2 s', waves r = 0), hB[parity] two rows further (2 s' + 1)
+    // H: this lane's store address for tile T of the step of parity p: + p * kHRowB + T * 2048
+    const uint32_t hw0 = smem_base + kRingB + (r ? 2 * kHRowB : 0) + (lane & 15) * 128 + (((4 * h + 2 * hh + ((lane >> 4) & 1)) ^ (lane & 7)) * 16);
+    // V: thread -> pooled column 32 * half + tid / 8, chunk tid & 7 (8 channels): one 16-byte read per row, one 16-byte store
+    const int vpx = tid >> 3, vc = tid & 7;
+    const uint32_t vr0 = smem_base + kRingB + vpx * 128 + ((vc ^ (vpx & 7)) * 16);            // hA[0], columns 0..31; hB: + 2 * kHRowB; columns 32..63: + 4096
+    uint16_t* const vout = a.out + (size_t)b * (66 * 66 * 64) + (size_t)(band * (RB / 2) + 1) * (66 * 64) + (size_t)(vpx + 1) * 64 + vc * 8;
+    uint32_t oprev[4] = {0u, 0u, 0u, 0u};
+    u32x4 carry_lo = {0u, 0u, 0u, 0u}, carry_hi = {0u, 0u, 0u, 0u};     // conv row 2 s' - 1, pooled horizontally (image top: zeros -- post-ReLU values are >= 0)
+    u32x4 va, vb;
+    f32x16 acc[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[2][e] = 0.0f; acc[3][e] = 0.0f; }
+    int st = 0, s = s0;
+    for (int i = tid; i < 4 * kHRowB / 16; i += 256)           // (the weight staging area is free: every wave passed the barrier behind its reads)
+        reinterpret_cast<uint4*>(smem + kRingB)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // horizontal pool of (tile T, register pair k / k + 4): conv1_pool32_kernel's statements, in five micro-steps of two instructions --
+    // a wave issues in order, so whatever rides in a slot delays that slot's MFMA by its issue time: a whole piece (ten instructions)
+    // in one slot cost as much as it saved (first form: K loop 8.2 k -> 9.5 k cycles), two instructions fit beside the 32 cycles
+    uint32_t m[4], hx_a = 0u, hx_b = 0u, hx_e = 0u, hx_o = 0u, hx_w = 0u;
+    auto hmicro = [&](auto T_, auto k_, auto ph_) {
+        constexpr int T = decltype(T_)::value, k = decltype(k_)::value, ph = decltype(ph_)::value;
+        if constexpr (ph == 0) { hx_a = Elem<F16>::pack2(acc[T][2 * k], acc[T][2 * k + 1]); hx_b = Elem<F16>::pack2(acc[T][2 * k + 8], acc[T][2 * k + 9]); }
+        if constexpr (ph == 1) { hx_a = pk_relu16(hx_a); hx_b = pk_relu16(hx_b); }
+        if constexpr (ph == 2) { const auto sw = __builtin_amdgcn_permlane16_swap(hx_a, hx_b, false, false); hx_e = sw[0]; hx_o = sw[1]; }
+        if constexpr (ph == 3) { hx_w = T > 0 ? dpp<kDppRor1>(hx_e, oprev[k]) : hx_e; hx_e = pk_max_u16(hx_e, hx_o); }
+        if constexpr (ph == 4) { const uint32_t bl = dpp<kDppShr1>(hx_w, hx_o); m[k] = pk_max_u16(hx_e, bl); oprev[k] = hx_o; }
+    };
+    auto hpiece = [&](auto T_, auto k_) {
+        using std::integral_constant;
+        hmicro(T_, k_, integral_constant<int, 0>{}); hmicro(T_, k_, integral_constant<int, 1>{}); hmicro(T_, k_, integral_constant<int, 2>{});
+        hmicro(T_, k_, integral_constant<int, 3>{}); hmicro(T_, k_, integral_constant<int, 4>{});
+    };
+    auto hstore = [&](auto T_, int parity) {
+        constexpr int T = decltype(T_)::value;
+        const uint32_t ad = hw0 + (uint32_t)parity * kHRowB;
+        const u32x4 v = {m[0], m[1], m[2], m[3]};
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ad), "v"(v), "n"(T * 2048) : "memory");
+    };
+    auto vread = [&](auto HALF_, int parity) {                 // pooled rows 2 s', 2 s' + 1 of the step of this parity
+        constexpr int HALF = decltype(HALF_)::value;
+        const uint32_t ad = vr0 + (uint32_t)parity * kHRowB;
+        u32x4 ra, rb;                                          // (asm operands cannot name a capture of a generic lambda)
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                     : "=&v"(ra), "=&v"(rb) : "v"(ad), "n"(HALF * 4096), "n"(HALF * 4096 + 2 * kHRowB) : "memory");
+        va = ra; vb = rb;
+    };
+    u32x4 vo4;
+    auto vmicro = [&](auto HALF_, auto ph_, int sp) {          // sp = the step the rows belong to (relative to the band; < 0: the halo step)
+        constexpr int HALF = decltype(HALF_)::value, ph = decltype(ph_)::value;
+        u32x4& carry = HALF ? carry_hi : carry_lo;
+        if constexpr (ph < 4) vo4[ph] = pk_max_u16(pk_max_u16(va[ph], vb[ph]), carry[ph]);
+        if constexpr (ph == 4) {
+            carry = vb;
+            if (sp >= 0) *reinterpret_cast<u32x4*>(vout + (size_t)sp * (66 * 64) + HALF * (32 * 64)) = vo4;
+        }
+    };
+    auto vfinish = [&](auto HALF_, int sp) {
+        using std::integral_constant;
+        vmicro(HALF_, integral_constant<int, 0>{}, sp); vmicro(HALF_, integral_constant<int, 1>{}, sp); vmicro(HALF_, integral_constant<int, 2>{}, sp);
+        vmicro(HALF_, integral_constant<int, 3>{}, sp); vmicro(HALF_, integral_constant<int, 4>{}, sp);
+    };
+    using std::integral_constant;
+    // the K loop's riders, one micro-step per slot: H_B(s - 1) in slots 2..41 (tiles 2, 3), V_lo(s - 1) read at 46 / finished in 58..62,
+    // V_hi(s - 2) read at 64 / finished in 76..80, H_A(s) in slots 116..155 (tiles 0, 1: final since slot 112).  No guards for the
+    // band's first steps (a compare and a branch per slot would ride too): the riders that run before their step exists pool ZEROS --
+    // pair B's accumulators and the four pooled-row buffers start as zeros -- into rows that are never stored (step < 0) and leave
+    // the carried row zero, which is what the image's top wants and what the halo step of a lower band overwrites before it is used
+    auto ride = [&](auto n_) {
+        constexpr int N = decltype(n_)::value;
+        if constexpr (N >= 2 && N < 42) {
+            constexpr int i = (N - 2) / 5, T = 2 + i / 4, k = i % 4, ph = (N - 2) % 5;
+            hmicro(integral_constant<int, T>{}, integral_constant<int, k>{}, integral_constant<int, ph>{});
+            if constexpr (k == 3 && ph == 4) hstore(integral_constant<int, T>{}, (s - 1) & 1);
+        }
+        if constexpr (N == 46) vread(integral_constant<int, 0>{}, (s - 1) & 1);
+        if constexpr (N >= 58 && N < 63) vmicro(integral_constant<int, 0>{}, integral_constant<int, N - 58>{}, s - 1);
+        if constexpr (N == 64) vread(integral_constant<int, 1>{}, (s - 2) & 1);
+        if constexpr (N >= 76 && N < 81) vmicro(integral_constant<int, 1>{}, integral_constant<int, N - 76>{}, s - 2);
+        if constexpr (N >= 116 && N < 156) {
+            constexpr int i = (N - 116) / 5, T = i / 4, k = i % 4, ph = (N - 116) % 5;
+            hmicro(integral_constant<int, T>{}, integral_constant<int, k>{}, integral_constant<int, ph>{});
+            if constexpr (k == 3 && ph == 4) hstore(integral_constant<int, T>{}, s & 1);
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SSTAMPK(1);
+
+    for (; st < nsteps; ++st, ++s) {
+        SSTAMP(2);
+        const int n0 = 4 * st;
+        if (st + 1 < nsteps) issue_row(n0 + 9 + wave);
+        uint32_t xa[7];
+#pragma unroll
+        for (int kr = 0; kr < 7; ++kr) xa[kr] = smem_base + (uint32_t)(((n0 + 2 * r + kr) % kRing) * kPitch) + lane_off;
+        bf16x8 xf[8];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // slots 0..6 = (g 0: tiles 0, 1), (g 1: 0, 1), (g 2: 0, 1), (g 3: 0)
+        xf[0] = lds_read_2xb64<0>(xa[0]); xf[1] = lds_read_2xb64<2304>(xa[0]); xf[2] = lds_read_2xb64<32>(xa[0]); xf[3] = lds_read_2xb64<32 + 2304>(xa[0]);
+        xf[4] = lds_read_2xb64<64>(xa[0]); xf[5] = lds_read_2xb64<64 + 2304>(xa[0]); xf[6] = lds_read_2xb64<96>(xa[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        stem32r_slots<F16>(acc, xf, wreg, xa, bias_v, ride, std::make_integer_sequence<int, kSlots32>{});
+        SSTAMP(3);
+        SSTAMP(4);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        SSTAMP(5);
+        __builtin_amdgcn_s_barrier();       // the step's ONE barrier: ring rows of the next step landed and published, this step's ring rows and H_A / H_B buffers handed over
+        SSTAMP(6);
+        SSTAMP(7);
+        SSTAMP(8);
+    }
+    // ---- what has not ridden yet: H_B of the last step, then V_hi(last - 1), V_lo(last), V_hi(last)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[2]), "+v"(acc[3]));
+    {
+        using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>; using I2 = integral_constant<int, 2>; using I3 = integral_constant<int, 3>;
+        const int sl = s - 1;                                  // the last step
+        hpiece(I2{}, I0{}); hpiece(I2{}, I1{}); hpiece(I2{}, I2{}); hpiece(I2{}, I3{}); hstore(I2{}, sl & 1);
+        hpiece(I3{}, I0{}); hpiece(I3{}, I1{}); hpiece(I3{}, I2{}); hpiece(I3{}, I3{}); hstore(I3{}, sl & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        vread(I1{}, (sl - 1) & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+        vfinish(I1{}, sl - 1);
+        vread(I0{}, sl & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+        vfinish(I0{}, sl);
+        vread(I1{}, sl & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va), "+v"(vb)::"memory");
+        vfinish(I1{}, sl);
+    }
+    SSTAMPK(9);
+}
+
 }  // namespace
 
 namespace spsp {
 
 // conv1 + BN + ReLU + max-pool for B crops: in = native [B][262][264][18], out = [B][66][66][64] (interior).
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band, bool mfma32) {
+                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band, int mfma32) {
     SPSP_REQUIRE(in && w && bias && out && B > 0, "conv_stem: bad arguments");
     SPSP_REQUIRE(rows_per_band == 0 || (rows_per_band >= 4 && rows_per_band <= 128 && (rows_per_band & (rows_per_band - 1)) == 0),
                  "conv_stem: bands of %d conv rows (a power of two, 4 .. 128)", rows_per_band);
@@ -591,6 +845,8 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool_kernel<true>>(kLds));
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool32_kernel<false>>(kLds));
     SPSP_TRY(ensure_dynamic_lds<&conv1_pool32_kernel<true>>(kLds));
+    SPSP_TRY(ensure_dynamic_lds<&conv1_pool32r_kernel<false>>(kLds32r));
+    SPSP_TRY(ensure_dynamic_lds<&conv1_pool32r_kernel<true>>(kLds32r));
     a.dbg = nullptr;
 #ifdef SPSP_CONV_STAMPS
     if (getenv("SPSP_CONV_DEBUG")) {
@@ -598,7 +854,8 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
         const int diag = getenv("SPSP_STEM_DIAG") ? atoi(getenv("SPSP_STEM_DIAG")) : 0;
         (void)ensure_dynamic_lds<&conv1_pool_kernel<true, 1>>(kLds);
         (void)ensure_dynamic_lds<&conv1_pool_kernel<true, 2>>(kLds);
-        if (mfma32 && diag == 0) { if (f16) conv1_pool32_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a); else conv1_pool32_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a); }
+        if (mfma32 == 1 && diag == 0) { if (f16) conv1_pool32r_kernel<true><<<dim3(B * a.bands), 256, kLds32r, st>>>(a); else conv1_pool32r_kernel<false><<<dim3(B * a.bands), 256, kLds32r, st>>>(a); }
+        else if (mfma32 && diag == 0) { if (f16) conv1_pool32_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a); else conv1_pool32_kernel<false><<<dim3(B * a.bands), 256, kLds, st>>>(a); }
         else if (diag == 1) conv1_pool_kernel<true, 1><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         else if (diag == 2) conv1_pool_kernel<true, 2><<<dim3(B * a.bands), 256, kLds, st>>>(a);
         else if (f16) conv1_pool_kernel<true><<<dim3(B * a.bands), 256, kLds, st>>>(a);
@@ -607,12 +864,15 @@ int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, u
         unsigned long long hh[16];
         (void)hipMemcpy(hh, a.dbg, sizeof hh, hipMemcpyDeviceToHost);
         fprintf(stderr, "stem[%s diag %d] wg9 (band 1, 9 steps): prologue %llu | step3: K loop %llu | h-pool + LDS writes %llu | vmcnt/lgkm wait %llu | barrier %llu | vertical + stores %llu | barrier %llu | whole kernel %llu cycles\n",
-                mfma32 ? "32x32x16" : "16x16x32", diag, hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
+                mfma32 == 1 ? "32x32x16, pooling in the K loop" : mfma32 ? "32x32x16" : "16x16x32", diag, hh[1] - hh[0], hh[3] - hh[2], hh[4] - hh[3], hh[5] - hh[4], hh[6] - hh[5], hh[7] - hh[6], hh[8] - hh[7], hh[9] - hh[0]);
         (void)hipFree(a.dbg);
         return SPSP_OK;
     }
 #endif
-    if (mfma32) {
+    if (mfma32 == 1) {
+        if (f16) launch_kernel(&conv1_pool32r_kernel<true>, dim3(B * a.bands), dim3(256), kLds32r, st, a);
+        else launch_kernel(&conv1_pool32r_kernel<false>, dim3(B * a.bands), dim3(256), kLds32r, st, a);
+    } else if (mfma32) {
         if (f16) launch_kernel(&conv1_pool32_kernel<true>, dim3(B * a.bands), dim3(256), kLds, st, a);
         else launch_kernel(&conv1_pool32_kernel<false>, dim3(B * a.bands), dim3(256), kLds, st, a);
     } else if (f16) launch_kernel(&conv1_pool_kernel<true, 0>, dim3(B * a.bands), dim3(256), kLds, st, a);

@@ -297,7 +297,7 @@ struct spsp_regressor {
     uint16_t* wq2 = nullptr; // layer2.0's 3x3 / 2 + 1x1 / 2 pair as register-order MFMA fragments (conv_s2q.hip)
     bool use_s2q = true;   // layer2.0 on conv_s2q.hip (all 128 output channels per workgroup); off: conv_s2rs.hip (SPSP_DEBUG_PLAN_S2Q)
     uint16_t* wfb[2];      // layer1's two BasicBlocks: both convolutions' weights as register-order MFMA fragments (conv_fb.hip)
-    bool stem32 = true;    // the stem on v_mfma_f32_32x32x16 (conv1_pool32_kernel); off: the 16x16x32 form (SPSP_DEBUG_PLAN_STEM32)
+    int stem32 = 1;        // the stem on v_mfma_f32_32x32x16: 1 = pooling inside the K loop (conv1_pool32r_kernel), 2 = behind it (conv1_pool32_kernel); 0: the 16x16x32 form (SPSP_DEBUG_PLAN_STEM32)
     bool use_fb = true;    // layer1: one launch per BasicBlock (conv_fb.hip); off: two conv_wres launches per block (SPSP_DEBUG_PLAN_FB)
     float *w1f, *w13, *w2, *w3;   // IEF weights in the fused kernel's form (see ief_fused_kernel)
     float *cvec, *b2, *p0;
@@ -786,7 +786,7 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             r->rs_wgs = value;
             return SPSP_OK;
         case SPSP_DEBUG_PLAN_FB: r->use_fb = value != 0; return SPSP_OK;
-        case SPSP_DEBUG_PLAN_STEM32: r->stem32 = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_PLAN_STEM32: if (value < 0 || value > 2) return SPSP_EINVAL; r->stem32 = value; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2Q: r->use_s2q = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2: r->use_s2 = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_S2RS: r->use_s2rs = value != 0; return SPSP_OK;

@@ -455,9 +455,13 @@ def test_layer2_layer3_without_the_k_split_match_the_k_split_kernel(dev):
 
 
 def test_stem_on_32x32x16_mfma_matches_the_16x16x32_form(dev):
-    """csrc/conv_stem.hip, conv1_pool32_kernel (round 5, the default): conv1 + BN + ReLU + max-pool on v_mfma_f32_32x32x16 -- one MFMA per
+    """csrc/conv_stem.hip, conv1_pool32r_kernel (round 5, the default): conv1 + BN + ReLU + max-pool on v_mfma_f32_32x32x16 -- one MFMA per
     32 cycles for a loop that is bound by its issue slots, even / odd conv columns in even / odd 16-lane rows, the horizontal pool by
-    v_permlane16_swap + a DPP row shift -- against the 16x16x32 kernel of rounds 1-4 (`SPSP_DEBUG_PLAN_STEM32` = 0).  The same products
+    v_permlane16_swap + a DPP row shift, and both pools RIDING in the K loop of the following step(s): pixel tiles as two pairs, pooled
+    rows two deep by step parity, the row above carried in registers, one barrier per step -- (i) bit for bit against the same MFMAs
+    with the pooling behind the loop (`SPSP_DEBUG_PLAN_STEM32` = 2: conv1_pool32_kernel), at every band height from the 4-row bands of B = 1 and 3
+    (two and three steps per workgroup: every guard of the riding schedule) to 64 rows; (ii) against the 16x16x32 kernel of rounds 1-4
+    (`SPSP_DEBUG_PLAN_STEM32` = 0).  The same products
     summed in another order (56 MFMAs of depth 16 per output instead of 28 of depth 32): the pooled map within one unit in the last
     place of the element type at its largest value, the regressor outputs within 1e-4 / 5e-4; B = 32, 22 (16-row bands), 3 and 1
     (finer bands), the band heights of plan "throughput", both element types.  Against the rounding-emulating oracle in the stage
@@ -472,15 +476,15 @@ def test_stem_on_32x32x16_mfma_matches_the_16x16x32_form(dev):
             x, _ = S.proxy_crops(B, seed=110 + B)
             native = reg.pack(torch.from_numpy(x).to(dev))
             got = {}
-            for m32, band in ((0, 0), (1, 0), (1, 32), (1, 64)):
+            for m32, band in ((0, 0), (1, 0), (1, 32), (1, 64), (2, 0), (2, 64)):
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM32, m32), 'debug')
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM_BAND, band), 'debug')
                 out = [t.clone() for t in reg(native)] + [reg.read_stage(1, B).clone()]
                 torch.cuda.synchronize()
                 reg.check_status()
                 got[(m32, band)] = out
-            for band in (32, 64):            # which workgroup computes a row changes, nothing about the row
-                assert all(torch.equal(a, b) for a, b in zip(got[(1, 0)], got[(1, band)])), (prec, B, band)
+            for key in ((1, 32), (1, 64), (2, 0), (2, 64)):   # which workgroup computes a row, and when it is pooled, changes; nothing about the row
+                assert all(torch.equal(a, b) for a, b in zip(got[(1, 0)], got[key])), (prec, B, key, (got[(1, 0)][3] - got[key][3]).abs().max().item())
             ref, new = got[(0, 0)], got[(1, 0)]
             assert all(torch.isfinite(t).all() for t in new)
             scale = ref[3].abs().max().item()

@@ -12,6 +12,7 @@ from soccerplayershapepose_amd import _abi, synthetic as S  # noqa: E402
 from soccerplayershapepose_amd import runtime as rt  # noqa: E402
 from soccerplayershapepose_amd.models.regressor import SingleInputRegressor  # noqa: E402
 
+FORMS = ('16x16x32', '32x32x16, pooling in the K loop', '32x32x16, pooling behind the loop')
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = torch.device('cuda', 0)
 r = rt.get(dev)
@@ -24,7 +25,7 @@ for B in (32, 22):
     native = reg.pack(torch.from_numpy(x).to(dev))
     for rnd in range(2):
         for plan in ('latency', 'throughput'):
-            for m32 in (0, 1):
+            for m32 in (0, 2, 1):
                 reg.set_plan(plan)
                 r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_PLAN_STEM32, m32), 'debug')
                 reg(native)
@@ -39,4 +40,4 @@ for B in (32, 22):
                 r.check(r.lib.spsp_profile_read(r.ctx, nk, ms, cnt), 'read')
                 i = names.index('conv1_pool_kernel')
                 tot = sum(ms[j] for j in range(nk) if cnt[j] and names[j].startswith('conv')) * 1e3 / reps
-                print(f'B={B} plan {plan:10s} stem on {"32x32x16" if m32 else "16x16x32"}: {1e3 * ms[i] / cnt[i]:6.2f} us; all convolutions {tot:6.1f} us', flush=True)
+                print(f'B={B} plan {plan:10s} stem on {FORMS[m32]:34s}: {1e3 * ms[i] / cnt[i]:6.2f} us; all convolutions {tot:6.1f} us', flush=True)
