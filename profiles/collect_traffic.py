@@ -2,7 +2,9 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) into
 profiles/hbm_traffic.json: HBM bytes per launch for every kernel of the hot path.
 
-    python profiles/collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv>
+    python profiles/collect_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [<fetch> <write> of a plan-"throughput" run]
+
+(the second pair supplies the kernels only plan "throughput" launches; a kernel both runs launch keeps the first pair's bytes)
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB-like units of
 1024 B; on gfx950 FETCH_SIZE reports exactly HALF of the bytes of wide coalesced streaming reads (128-B requests
@@ -68,6 +70,11 @@ if __name__ != '__main__':
     raise SystemExit
 NAMES = library_names()
 fetch, write = per_kernel(sys.argv[1], NAMES), per_kernel(sys.argv[2], NAMES)
+if len(sys.argv) > 4:
+    fetch2, write2 = per_kernel(sys.argv[3], NAMES), per_kernel(sys.argv[4], NAMES)
+    for k in set(fetch2) | set(write2):
+        if k not in fetch and k not in write:
+            fetch[k], write[k] = fetch2.get(k, 0.0), write2.get(k, 0.0)
 out = {}
 for k in sorted(set(fetch) | set(write)):
     rd, wr = 2 * 1024 * fetch.get(k, 0.0), 1024 * write.get(k, 0.0)

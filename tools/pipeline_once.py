@@ -1,6 +1,6 @@
 """The whole hot path (regressor -> rot6d -> 50-iteration fit -> SMPL forward) at batch 32, a few times, one batch in
 flight: the command profiled by the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes behind profiles/hbm_traffic.json.
-usage: python tools/pipeline_once.py [B] [repeats] [players per skin workgroup: 8 | 16]"""
+usage: python tools/pipeline_once.py [B] [repeats] [players per skin workgroup: 8 | 16] [regressor plan: latency | throughput]"""
 import os
 import sys
 
@@ -22,6 +22,8 @@ smpl = SMPL(S.smpl_model(seed=0), max_batch=B).to(dev)
 if len(sys.argv) > 3:
     from soccerplayershapepose_amd import _abi
     smpl.debug(_abi.DEBUG_SKIN_PLAYERS, int(sys.argv[3]))
+if len(sys.argv) > 4:
+    reg.set_plan(sys.argv[4])
 x, _ = S.proxy_crops(B, seed=1)
 native = reg.pack(torch.from_numpy(x).to(dev))
 tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(3)) * 300 + 100).to(dev)
