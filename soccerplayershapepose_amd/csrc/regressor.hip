@@ -578,8 +578,9 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         // PROD) -- layer4's launch 18.2 -> 15.5 us (64-channel blocks), 13.0 -> 12.6 (32), layer3's 12.7 -> 12.1, bit-identical
         // results (tools/ab_plan.py, run g3aa); in the four-slot pipeline the gain is within the noise (+0.4 %, tools/ab_pipeline.py)
         const bool def_prod[4] = {false, false, true, true};
-        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; r->patch_prod[L] = def_prod[L] && !getenv("SPSP_NO_PATCH_PRODUCERS"); }
+        for (int L = 0; L < 4; ++L) { r->ring[L] = def_t[L]; r->patch_db[L] = def_db[L]; r->patch_tile[L] = def_tile[L]; r->patch_ring[L] = def_ring[L]; r->patch_nch[L] = def_nch[L]; r->patch_prod[L] = def_prod[L]; }
 #if defined(SPSP_TUNING) || defined(SPSP_CONV_STAMPS)   // experiment builds only (TUNING=1, or the stamped twin library)
+        if (getenv("SPSP_NO_PATCH_PRODUCERS")) for (int L = 0; L < 4; ++L) r->patch_prod[L] = false;
         if (const char* e = getenv("SPSP_PATCH_TILE")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_tile[0], &r->patch_tile[1], &r->patch_tile[2], &r->patch_tile[3]);
         if (const char* e = getenv("SPSP_PATCH_RING")) (void)sscanf(e, "%d,%d,%d,%d", &r->patch_ring[0], &r->patch_ring[1], &r->patch_ring[2], &r->patch_ring[3]);
         if (const char* e = getenv("SPSP_RING_TILE")) {      // RingTile enum values: 0 128x128s3, 1 128x128s2, 2 128x64s3, 3 128x64s4, 4 64x128s3, 5 64x64s4

@@ -1,6 +1,6 @@
 """The pipelined throughput mode alone (PlayerPipeline: 4 slots, HIP graphs, plan "throughput"; regressor -> fit -> SMPL at batch 32):
 the command tools/pipeline_occupancy.py's kernel trace is taken from.
-usage: python tools/pipeline_run.py [steps] [what=value,...]     (SPSP_DEBUG_PLAN_* hooks on every slot's regressor)"""
+usage: python tools/pipeline_run.py [steps] [what=value,...] [plan]     (SPSP_DEBUG_PLAN_* hooks on every slot's regressor; plan: auto | latency | throughput)"""
 import os
 import sys
 import time
@@ -31,7 +31,8 @@ def mk_r():
     return reg
 
 
-pipe = PlayerPipeline(mk_r, lambda: SMPL(model, max_batch=B), dev, depth=4, use_graphs=True)
+plan = sys.argv[3] if len(sys.argv) > 3 else 'auto'
+pipe = PlayerPipeline(mk_r, lambda: SMPL(model, max_batch=B), dev, depth=4, use_graphs=True, plan=plan)
 x, _ = S.proxy_crops(B, seed=1234)
 natives = [pipe.slots[0].regressor.pack(torch.from_numpy(x).to(dev)) for _ in range(4)]
 tgt = (torch.rand(B, 17, 2, generator=torch.Generator().manual_seed(3)) * 300 + 100).to(dev)
@@ -44,4 +45,4 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 assert torch.isfinite(out.vertices).all()
-print(f'{B * steps / dt:9.0f} players/s, {1e6 * dt / steps:6.1f} us per batch of {B} ({steps} steps, hooks {hooks})')
+print(f'{B * steps / dt:9.0f} players/s, {1e6 * dt / steps:6.1f} us per batch of {B} ({steps} steps, hooks {hooks}, plan {plan})')
