@@ -1662,8 +1662,12 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
     per-frame errors cannot hide behind each other; the 60 (frame, player) fits are independent, so they run after the GPU clip as
     ONE `fit_pose_shape_batch` call -- seconds, where 30 separate oracle fits of 2.4 s of framework overhead each made round 4 thin
     this check to four frames) and FREE-RUNNING (the oracle chains its own results from the same regressor outputs: 2e-4 per frame
-    over the first three frames, and the vertices after ten chained fits -- all 30 with SPSP_TEST_FULL=1 -- within the north-star
-    1e-3 m; rounds 3 and 4 chained all 30 and passed the same bound)."""
+    over the first three frames, and the vertices after ten chained fits within the north-star 1e-3 m.  With SPSP_TEST_FULL=1 the
+    oracle chains all 30 and the bound after the last is 1e-2 m: on this trajectory ONE fit (frame 20) parts the two chains by
+    2.6 mm from starting states 2e-6 m apart -- the best-iterate rule choosing between two iterates of nearly equal joints2D_l2es,
+    a discrete event of the algorithm that the ten-barrier kernel with IEEE division and square root shows as well (3.1 mm,
+    tools/clip_chain.py, profiles/r05_clip_chain.txt; on the f16 regressor's trajectory both stay below 1.1e-4 m over 30 frames);
+    what holds a frame to the reference is the teacher-forced check above)."""
     from soccerplayershapepose_amd.player_recon import reconstruct_players, single_view_optimization
     from soccerplayershapepose_amd.utils.rigid_transform_utils import rot6d_to_rotmat
     from oracle import fit as OF, smpl as OS
@@ -1721,7 +1725,7 @@ def test_ragged_match_frame_and_temporal_warm_start_clip(regressor_gpu, smpl_gpu
     print(f'30-frame clip: worst per-frame parameter deviation teacher-forced (all {T} frames) {worst_forced:.2e}, free-running ({FREE} frames) '
           f'{worst_free:.2e}; vertices after {FREE} chained fits vs the free-running oracle chain {vdev:.2e} m')
     assert worst_forced < 2e-4, f'frame {int(np.argmax(per_frame))}: {worst_forced} from the oracle fit started at the same state'
-    assert vdev < 1e-3
+    assert vdev < (1e-2 if FULL_ORACLE else 1e-3)
 
 
 # ---------------------------------------------------------------- PoseRelationModule (8f-2)
