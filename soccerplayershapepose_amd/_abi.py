@@ -24,7 +24,7 @@ OK, EINVAL, ENOMEM, EHIP, ENCCL = 0, -1, -2, -3, -4           # include/spsp.h s
 PROXY_NCHW_F32, PROXY_NATIVE = 0, 1
 PRECISION_BF16, PRECISION_F16 = 0, 1
 SIL_U8, SIL_F32 = 0, 1
-DEBUG_IEF_STALL, DEBUG_PLAN_S2, DEBUG_PLAN_LAYER4_CHANNELS, DEBUG_PLAN_PATCH, DEBUG_PLAN_PATCH_PRODUCER, DEBUG_PLAN_S2RS, DEBUG_PLAN_P4, DEBUG_PLAN_WRES_CUS, DEBUG_PLAN_STEM_BAND, DEBUG_PLAN_P4_CUS, DEBUG_PLAN_S2RS_CUS, DEBUG_IEF_BLOCK, DEBUG_PLAN_FB, DEBUG_PLAN_S2Q, DEBUG_PLAN_STEM32, DEBUG_PLAN_RS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
+DEBUG_IEF_STALL, DEBUG_PLAN_S2, DEBUG_PLAN_LAYER4_CHANNELS, DEBUG_PLAN_PATCH, DEBUG_PLAN_PATCH_PRODUCER, DEBUG_PLAN_S2RS, DEBUG_PLAN_P4, DEBUG_PLAN_WRES_CUS, DEBUG_PLAN_STEM_BAND, DEBUG_PLAN_P4_CUS, DEBUG_PLAN_S2RS_CUS, DEBUG_IEF_BLOCK, DEBUG_PLAN_FB, DEBUG_PLAN_S2Q, DEBUG_PLAN_STEM32, DEBUG_PLAN_RS, DEBUG_IEF_POLL = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
 DEBUG_FIT_SCHEDULE, DEBUG_SKIN_PLAYERS = 1, 2          # spsp_smpl_debug
 REGRESSOR_MAX_BATCH, REGRESSOR_MAX_CONCURRENT = 256, 8
 PLAN_THROUGHPUT, PLAN_LATENCY = 0, 1

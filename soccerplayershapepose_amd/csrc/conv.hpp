@@ -92,6 +92,7 @@ int launch_conv_fb(const uint16_t* in, const uint16_t* wf, const float* bias1, c
 // conv_stem.hip: conv1 + BN + ReLU + max-pool in one kernel: native input [B][262][264][18] -> pooled map [B][66][66][64];
 // its first workgroup also zeroes `nzero` words at `zero_words` (the counters of the forward's later kernels; may be NULL)
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t stream, int rows_per_band = 0, int mfma32 = 0);
+                     unsigned int* zero_words, int nzero, hipStream_t stream, int rows_per_band = 0, int mfma32 = 0,
+                     float* zero_wide = nullptr, int nzero_wide16 = 0);   // zero_wide: 16-byte words every workgroup zeroes a share of
 
 }  // namespace spsp

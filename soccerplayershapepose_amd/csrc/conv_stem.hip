@@ -97,6 +97,8 @@ struct StemArgs {
     int rows_per_band;       // conv rows per band: 16, 8 or 4 (a band = rows_per_band / 2 pool rows)
     unsigned int* zero;      // words the FIRST workgroup zeroes: the tile-scheduler / hand-off counters of the forward's later kernels
     int nzero;               //   (this is the forward's first kernel; a memset node in front of it cost ~5 us of every forward)
+    uint4* zero2;            // ... and 16-byte words EVERY workgroup zeroes a share of: the polling IEF's hand-off buffers (regressor.hip)
+    int nzero2;
     unsigned long long* dbg; // diagnostic builds (-DSPSP_CONV_STAMPS): s_memtime stamps of one workgroup
 };
 
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv1_pool_kernel(const StemArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blockIdx.x == 0)
         for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0u;
+    for (int i = blockIdx.x * 256 + tid; i < a.nzero2; i += gridDim.x * 256) a.zero2[i] = make_uint4(0u, 0u, 0u, 0u);
     SSTAMPK(0);
     const int h = wave & 1, r = wave >> 1;                    // channel half, conv row within the step
     const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void conv1_pool32_kernel(const StemArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blockIdx.x == 0)
         for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0u;
+    for (int i = blockIdx.x * 256 + tid; i < a.nzero2; i += gridDim.x * 256) a.zero2[i] = make_uint4(0u, 0u, 0u, 0u);
     SSTAMPK(0);
     const int h = wave & 1, r = wave >> 1;                    // channel half, conv row within the step
     const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
@@ -616,6 +620,7 @@ __global__ __launch_bounds__(256, 1) void conv1_pool32r_kernel(const StemArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blockIdx.x == 0)
         for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0u;
+    for (int i = blockIdx.x * 256 + tid; i < a.nzero2; i += gridDim.x * 256) a.zero2[i] = make_uint4(0u, 0u, 0u, 0u);
     SSTAMPK(0);
     const int h = wave & 1, r = wave >> 1;
     const int b = blockIdx.x / a.bands, band = blockIdx.x - b * a.bands;
@@ -818,13 +823,14 @@ namespace spsp {
 
 // conv1 + BN + ReLU + max-pool for B crops: in = native [B][262][264][18], out = [B][66][66][64] (interior).
 int launch_conv_stem(const uint16_t* in, const uint16_t* w, const float* bias, uint16_t* out, int B, int f16, int num_cus,
-                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band, int mfma32) {
+                     unsigned int* zero_words, int nzero, hipStream_t st, int rows_per_band, int mfma32, float* zero_wide, int nzero_wide16) {
     SPSP_REQUIRE(in && w && bias && out && B > 0, "conv_stem: bad arguments");
     SPSP_REQUIRE(rows_per_band == 0 || (rows_per_band >= 4 && rows_per_band <= 128 && (rows_per_band & (rows_per_band - 1)) == 0),
                  "conv_stem: bands of %d conv rows (a power of two, 4 .. 128)", rows_per_band);
     StemArgs a;
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.zero = zero_words; a.nzero = zero_words ? nzero : 0;
+    a.zero2 = reinterpret_cast<uint4*>(zero_wide); a.nzero2 = zero_wide ? nzero_wide16 : 0;
     // bands of 16 conv rows (8 per image) fill 256 CUs at 32 crops with one halo step in nine; smaller batches take
     // finer bands so that the grid still covers the chip
     // (cost of a band height = rounds of workgroups x a workgroup's life, prologue 13 k + 12 k cycles per step of two conv rows --

@@ -117,6 +117,7 @@ struct IefArgs {
     const float *feats, *w1f, *w13, *w2, *w3;   // [512][512] x3, [157][512]
     const float *cvec, *b2, *p0;                // c_i [iters][512], b2 [512], init + iters*b3 [157]
     float *h1, *s;                              // [B][512] each: written and re-read across workgroups (never const/restrict)
+    float* hid;                                 // the polling form: [block of 16 players][phase 2 iters][neuron block 64][player 16][8], zero = not written yet
     float *cam, *pose, *betas;
     unsigned int* counters;                     // one monotonic arrival counter per block of 32 players
     unsigned int* err;                          // host-visible status word of the handle: a hand-off that timed out sets bit 0
@@ -272,6 +273,113 @@ __global__ __launch_bounds__(8 * PPB) void ief_fused_kernel(const IefArgs a) {
     }
 }
 
+// ---- round 5: hand-offs WITHOUT a counter -- the data is its own flag ---------------------------------------------------------------
+// A hand-off of ief_fused_kernel costs two trips across the fabric: the arrival counter (drain, barrier, atomic add, poll), then the
+// sc1 loads of the handed-off vector.  Every hidden value is >= +0 (a ReLU output or a sum of them), so it is STORED NEGATED -- its
+// sign bit always set, -0.0 included -- into a buffer that starts as zeros, one buffer per phase, and a consumer simply loads the
+// 2 x 8 float4 it needs (sc1) until none of the 64 words is zero: one trip.  The negation is undone by the FMA's source modifier,
+// so the sums are ief_fused_kernel's bit for bit.  No workgroup barrier anywhere: a wave leaves its poll loop when all its lanes
+// have their data (the DPP row sums need the whole row).  The buffers are zeroed by the forward's first kernel (the stem, every
+// workgroup a share: 393 KB at B = 32) -- or by a memset when the IEF is called without a backbone call in front.
+constexpr int kIefPhaseFloats = kIefG * 16 * 8;     // one phase of one block of 16 players: 32 KB
+
+__device__ __forceinline__ bool ief_load_poll(const float* x0, const float* x1, int s, float4 (&xa)[8], float4 (&xb)[8], unsigned int spin_limit) {
+    unsigned int spins = 0;
+    for (;;) {
+        ief_load_sc1<16>(x0, x1, s, true, xa, xb);
+        unsigned int m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            m = min(m, min(__builtin_bit_cast(unsigned int, xa[u].x), __builtin_bit_cast(unsigned int, xa[u].y)));
+            m = min(m, min(__builtin_bit_cast(unsigned int, xa[u].z), __builtin_bit_cast(unsigned int, xa[u].w)));
+            m = min(m, min(__builtin_bit_cast(unsigned int, xb[u].x), __builtin_bit_cast(unsigned int, xb[u].y)));
+            m = min(m, min(__builtin_bit_cast(unsigned int, xb[u].z), __builtin_bit_cast(unsigned int, xb[u].w)));
+        }
+        if (__builtin_amdgcn_ballot_w64(m == 0u) == 0ull) return true;
+        if (++spins > spin_limit) return false;           // (wave-uniform: the ballot is)
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// ief_product on a polled (negated) vector: the same FMAs in the same order, the stored sign undone by the source modifier
+__device__ __forceinline__ float ief_product_poll(const float* wl, const float* x0, const float* x1, int s, unsigned int spin_limit, bool& ok) {
+    float4 xa[8], xb[8];
+    ok &= ief_load_poll(x0, x1, s, xa, xb, spin_limit);
+    float mine = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 w = *reinterpret_cast<const float4*>(wl + n * 512 + 4 * (16 * u + s));
+            a0 = fmaf(w.x, -xa[u].x, a0); a0 = fmaf(w.y, -xa[u].y, a0); a0 = fmaf(w.z, -xa[u].z, a0); a0 = fmaf(w.w, -xa[u].w, a0);
+            a1 = fmaf(w.x, -xb[u].x, a1); a1 = fmaf(w.y, -xb[u].y, a1); a1 = fmaf(w.z, -xb[u].z, a1); a1 = fmaf(w.w, -xb[u].w, a1);
+        }
+        a0 = ief_row_sum(a0);
+        a1 = ief_row_sum(a1);
+        mine = s == n ? a0 : (s == n + 8 ? a1 : mine);
+    }
+    return mine;
+}
+
+__global__ __launch_bounds__(128) void ief_poll_kernel(const IefArgs a) {
+    extern __shared__ __align__(16) float ief_w[];           // [4][8][512]: W1f, W13, W2, W3 rows 8g..8g+7
+    constexpr int PPB = 16, NT = 128;
+    const int t = threadIdx.x, g = blockIdx.x, pb = blockIdx.y;
+    const int s = t & 15, pair = t >> 4;
+    const int bA = pb * PPB + 2 * pair, bB = bA + 1;
+    const int n = 8 * g + (s & 7);
+    const int b = (s >> 3) ? bB : bA;
+    const bool live = b < a.B;
+    const int rA = bA < a.B ? bA : a.B - 1, rB = bB < a.B ? bB : a.B - 1;
+    {
+        const float* src[4] = {a.w1f, a.w13, a.w2, a.w3};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 1024 / NT; ++q) {
+                const int e = 4 * (t + NT * q);
+                const int row = 8 * g + e / 512;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < 3 || row < kNPar) v = *reinterpret_cast<const float4*>(src[m] + (size_t)row * 512 + e % 512);
+                *reinterpret_cast<float4*>(ief_w + m * 4096 + e) = v;
+            }
+    }
+    __syncthreads();
+    float* const hid = a.hid + (size_t)pb * (2 * a.iters) * kIefPhaseFloats;      // phase 2 it: h1 of iteration it; 2 it + 1: S after it
+    const int mine = g * NT + t;                                                   // [g][player][8]: thread t float t, a 128-byte line per wave-store
+    const int pA = 2 * pair, pB = 2 * pair + 1;
+    bool ok = true;
+    const float f1 = ief_product<PPB>(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s, false);
+    __hip_atomic_store(hid + mine, -fmaxf(f1 + a.cvec[n], 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float ssum = 0.f;
+    const float b2 = a.b2[n];
+    for (int it = 0; it < a.iters; ++it) {
+        float* const h1p = hid + (size_t)(2 * it) * kIefPhaseFloats;
+        float* const sp = h1p + kIefPhaseFloats;
+        if (it > 0) {
+            const float* const sprev = h1p - kIefPhaseFloats;
+            const float v = ief_product_poll(ief_w + 4096, sprev + pA * 8, sprev + pB * 8, s, a.spin_limit, ok);
+            __hip_atomic_store(h1p + mine, -fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float v = ief_product_poll(ief_w + 2 * 4096, h1p + pA * 8, h1p + pB * 8, s, a.spin_limit, ok);
+        ssum += fmaxf(b2 + v, 0.f);
+        __hip_atomic_store(sp + mine, -ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (8 * g < kNPar) {
+        const float* const slast = hid + (size_t)(2 * a.iters - 1) * kIefPhaseFloats;
+        float v = a.p0[n < kNPar ? n : 0] + ief_product_poll(ief_w + 3 * 4096, slast + pA * 8, slast + pB * 8, s, a.spin_limit, ok);
+        if (!ok) v = __builtin_nanf("");
+        if (live && n < kNPar) {
+            if (n < 3) a.cam[b * 3 + n] = v;
+            else if (n < 147) a.pose[(size_t)b * 144 + (n - 3)] = v;
+            else a.betas[b * 10 + (n - 147)] = v;
+        }
+    }
+    // a poll that gave up: NaN outputs (above, where this workgroup has any) and the handle's host-visible status word
+    if (!ok && (t & 63) == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // IEF with no iterations (never used by the reference): outputs = the initial estimate
 __global__ void ief_init_only_kernel(const float* __restrict__ init, int B, float* __restrict__ cam, float* __restrict__ pose, float* __restrict__ betas) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,6 +452,9 @@ struct spsp_regressor {
     // workgroup does, with the tile-scheduler words); an IEF call uses them up.  spsp_regressor_ief on a handle whose counters are
     // not fresh (IEF run twice on the same features, IEF before any backbone) zeroes its eight lines itself with a memset node.
     bool ief_counters_fresh = false;
+    float* ief_hid = nullptr;           // the polling IEF's per-phase hand-off buffers (zeroed by every forward's stem kernel)
+    size_t ief_hid_block = 0;           // floats per block of 16 players: 2 iters x 32 KB
+    int ief_poll = 1;                   // 1: ief_poll_kernel (the data is its own flag), 0: ief_fused_kernel (arrival counters; SPSP_DEBUG_IEF_POLL)
     int ief_block = 16;                 // players per IEF block (64 workgroups that hand off to each other): 32, or 16 = two independent halves
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
@@ -551,6 +662,9 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ief_fused_kernel<32>, 256, kIefLds) != hipSuccess) per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_fused_kernel<16>, 128, kIefLds) != hipSuccess) per_cu16 = 0;
         if (per_cu16 < per_cu) per_cu = per_cu16;
+        TRY(ensure_dynamic_lds<&ief_poll_kernel>(kIefLds));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_poll_kernel, 128, kIefLds) != hipSuccess) per_cu16 = 0;
+        if (per_cu16 < per_cu) per_cu = per_cu16;
         r->ief_capacity = per_cu * ctx->num_cus;
         if (w->ief_iters > 0 && r->ief_capacity < kIefG * SPSP_REGRESSOR_MAX_CONCURRENT) {
             const int cap = r->ief_capacity;
@@ -600,6 +714,8 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
     TRY(r->pool.alloc(&r->feats, (B + 1) * kFeat));
     TRY(r->pool.alloc(&r->h1, (B + 31) / 32 * 32 * kHid));      // blocked hand-off layout: whole blocks of 32 players
     TRY(r->pool.alloc(&r->h2, (B + 31) / 32 * 32 * kHid));
+    r->ief_hid_block = (size_t)2 * (w->ief_iters > 0 ? w->ief_iters : 1) * kIefPhaseFloats;
+    TRY(r->pool.alloc(&r->ief_hid, (size_t)((B + 15) / 16) * r->ief_hid_block, true));
 #undef TRY
     *out = r;
     return SPSP_OK;
@@ -643,7 +759,10 @@ int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy,
     // stem: conv1 + BN + ReLU + max-pool in ONE kernel (conv_stem.hip); the 128 x 128 x 64 map is never materialised
     {
         ProfScope ps(ctx, kKStem, st, true);
-        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st, r->stem_band, r->stem32));
+        // ... and the polling IEF's hand-off buffers of the blocks of 16 players this batch's rows touch, every workgroup a share
+        const int blk0 = feat_row / 16, blk1 = (feat_row + B + 15) / 16;
+        TRY(launch_conv_stem(x0, r->w[0], r->bias[0], r->p1, B, r->f16, ctx->num_cus, r->counters, kCounterWords, st, r->stem_band, r->stem32,
+                             r->ief_hid + (size_t)blk0 * r->ief_hid_block, (int)((size_t)(blk1 - blk0) * r->ief_hid_block / 4)));
     }
     r->stage_ptr[0] = nullptr;
     r->stage_ptr[1] = r->p1;
@@ -712,11 +831,14 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
         IefArgs ia;
         ia.feats = r->feats; ia.w1f = r->w1f; ia.w13 = r->w13; ia.w2 = r->w2; ia.w3 = r->w3;
         ia.cvec = r->cvec; ia.b2 = r->b2; ia.p0 = r->p0;
-        ia.h1 = r->h1; ia.s = r->h2; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
+        ia.h1 = r->h1; ia.s = r->h2; ia.hid = r->ief_hid; ia.cam = cam; ia.pose = pose6d; ia.betas = betas;
         ia.counters = r->counters + 32 * 32;     // lines 32..39 of the per-forward counter block (zeroed by the backbone call)
         // ... or here, when no backbone call has run since the last IEF on this handle: with used-up counters every hand-off
         // of the launch would pass at once and the kernel would read hidden vectors that are not written yet
-        if (!r->ief_counters_fresh) SPSP_HIP_CHECK(hipMemsetAsync(ia.counters, 0, kIefCounterLines * 32 * sizeof(unsigned int), st));
+        if (!r->ief_counters_fresh) {
+            SPSP_HIP_CHECK(hipMemsetAsync(ia.counters, 0, kIefCounterLines * 32 * sizeof(unsigned int), st));
+            SPSP_HIP_CHECK(hipMemsetAsync(r->ief_hid, 0, (size_t)((B + 15) / 16) * r->ief_hid_block * sizeof(float), st));
+        }
         r->ief_counters_fresh = false;
         ia.B = B; ia.iters = r->ief_iters;
         ia.err = r->err_dev;
@@ -729,8 +851,10 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
         }
         SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel<32>>(kIefLds));
         SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel<16>>(kIefLds));
+        SPSP_TRY(ensure_dynamic_lds<&ief_poll_kernel>(kIefLds));
         ProfScope ps(ctx, kKIefFc, st, true);
-        if (ppb == 16) launch_kernel(&ief_fused_kernel<16>, dim3(ief_wgs, npb), dim3(128), kIefLds, st, ia);
+        if (r->ief_poll) launch_kernel(&ief_poll_kernel, dim3(ief_wgs, (B + 15) / 16), dim3(128), kIefLds, st, ia);
+        else if (ppb == 16) launch_kernel(&ief_fused_kernel<16>, dim3(ief_wgs, npb), dim3(128), kIefLds, st, ia);
         else launch_kernel(&ief_fused_kernel<32>, dim3(ief_wgs, npb), dim3(256), kIefLds, st, ia);
     } else {
         ProfScope ps(ctx, kKIefMisc, st);
@@ -782,6 +906,7 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             SPSP_REQUIRE(value == 16 || value == 32, "spsp_regressor_debug: IEF blocks of %d players (16 or 32)", value);
             r->ief_block = value;
             return SPSP_OK;
+        case SPSP_DEBUG_IEF_POLL: r->ief_poll = value != 0; return SPSP_OK;
         case SPSP_DEBUG_PLAN_RS:
             SPSP_REQUIRE(value == 0 || (value >= 2 && value <= 512 && value % 2 == 0), "spsp_regressor_debug: conv_rs on %d workgroups (0: off; even)", value);
             r->rs_wgs = value;

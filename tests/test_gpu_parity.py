@@ -380,6 +380,40 @@ def test_layer2_stride2_pair_with_all_channels_in_one_workgroup_matches_the_chan
             assert max((a - b).abs().max().item() for a, b in zip(new[:3], ref[:3])) <= (1e-4 if prec == 'f16' else 5e-4), (prec, B)
 
 
+def test_ief_forms_are_bit_identical(dev):
+    """The fused IEF (csrc/regressor.hip): the default since round 5, `ief_poll_kernel` -- blocks of 16 players whose hand-offs need no
+    arrival counter: every hidden value is >= +0, is stored NEGATED (sign bit set) into a per-phase buffer that the forward's stem kernel
+    has zeroed, and a consumer loads until none of its words is zero -- against `ief_fused_kernel` with its counter hand-offs
+    (`SPSP_DEBUG_IEF_POLL` = 0) in blocks of 16 and of 32 players (`SPSP_DEBUG_IEF_BLOCK`).  The same sums in the same order (the stored
+    sign is undone by the FMA's source modifier): cam, pose6d and betas bit for bit at B = 32, 22 (a ragged last block: idle lanes
+    recompute the last player), 3, 1 and 72 (five blocks), and again on a second forward of the same handle (the buffers re-zeroed).
+    Against the oracle in the stage tests, which run the default."""
+    from soccerplayershapepose_amd import runtime as rt
+    from soccerplayershapepose_amd.models.regressor import SingleInputRegressor
+    sd = S.regressor_state_dict(seed=0)
+    r = rt.get(dev)
+    for B in (32, 22, 3, 1, 72):
+        reg = SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(sd).to(dev)
+        natives = []
+        for k in range(2):
+            x, _ = S.proxy_crops(B, seed=150 + B + 1000 * k)
+            natives.append(reg.pack(torch.from_numpy(x).to(dev)))
+        got = {}
+        for poll, blk in ((0, 32), (0, 16), (1, 16)):
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_IEF_POLL, poll), 'debug')
+            r.check(r.lib.spsp_regressor_debug(reg.handle, _abi.DEBUG_IEF_BLOCK, blk), 'debug')
+            outs = []
+            for nat in natives + natives[:1]:                   # three forwards in a row on the handle
+                outs += [t.clone() for t in reg(nat)]
+            torch.cuda.synchronize()
+            reg.check_status()
+            got[(poll, blk)] = outs
+        assert all(torch.isfinite(t).all() for t in got[(1, 16)])
+        assert not torch.equal(got[(1, 16)][0], got[(1, 16)][3])            # (the two inputs differ)
+        for key in ((0, 16), (1, 16)):
+            assert all(torch.equal(a, b) for a, b in zip(got[(0, 32)], got[key])), (B, key)
+
+
 def test_layer2_with_register_stationary_weights_matches_the_streaming_kernel(dev):
     """csrc/conv_rs.hip (round 5, plan "throughput"): layer2's three 3x3 / 1 convolutions with a 64-channel block's weights stationary
     in registers and persistent workgroups over 8 x 16-pixel tiles (`SPSP_DEBUG_PLAN_RS` = workgroups; 0 = conv_p4.hip, which streams
