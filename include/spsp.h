@@ -220,7 +220,7 @@ int spsp_regressor_status(spsp_regressor* r);
 #define SPSP_DEBUG_PLAN_WRES_CUS 8         /* layer1's persistent workgroups on 1 / value of the CUs (1, 2, 4, 8, 16): more tiles per resident weight set */
 #define SPSP_DEBUG_PLAN_P4 7               /* bit L set: the 3x3 stride-1 convs of layer L+1 on conv_p4.hip (256-pixel tiles, no K split, producer waves); default: bit 1 = layer2 */
 #define SPSP_DEBUG_PLAN_RS 16             /* layer2's 3x3 stride-1 convs on conv_rs.hip (a channel block's weights in registers, persistent) with this many workgroups; 0: conv_p4.hip.  Plan "throughput": 64, plan "latency": 0 */
-#define SPSP_DEBUG_IEF_POLL 17            /* 1 (default): the IEF whose hand-offs poll the data itself (ief_poll_kernel), 0: the arrival-counter forms (SPSP_DEBUG_IEF_BLOCK) */
+#define SPSP_DEBUG_IEF_POLL 17            /* the IEF whose hand-offs poll the data itself (ief_poll_kernel): 2 (default) with 32 lanes per player pair, 1 with 16 (the counter forms' sums bit for bit); 0: the arrival-counter forms (SPSP_DEBUG_IEF_BLOCK) */
 #define SPSP_DEBUG_PLAN_STEM32 15         /* the stem kernel: 1 (default) on v_mfma_f32_32x32x16 with the pooling inside the K loop, 2: the same MFMAs with the pooling behind the loop, 0: on 16x16x32 (rounds 1-4) */
 #define SPSP_DEBUG_PLAN_S2Q 14            /* 1 (default): layer2.0's stride-2 pair on conv_s2q.hip (all 128 output channels per workgroup), 0: conv_s2rs.hip (64-channel blocks) */
 #define SPSP_DEBUG_PLAN_FB 13             /* 1 (default): layer1 as one launch per BasicBlock (conv_fb.hip), 0: two launches per block (conv_wres.hip) */

@@ -283,13 +283,37 @@ __global__ __launch_bounds__(8 * PPB) void ief_fused_kernel(const IefArgs a) {
 // workgroup a share: 393 KB at B = 32) -- or by a memset when the IEF is called without a backbone call in front.
 constexpr int kIefPhaseFloats = kIefG * 16 * 8;     // one phase of one block of 16 players: 32 KB
 
-__device__ __forceinline__ bool ief_load_poll(const float* x0, const float* x1, int s, float4 (&xa)[8], float4 (&xb)[8], unsigned int spin_limit) {
+// 2 x U float4 of the two players' k-slices (U = 128 / KS; KS lanes share a product), sc1
+template <int KS>
+__device__ __forceinline__ void ief_load_sc1_ks(const float* x0, const float* x1, int s, float4 (&xa)[128 / KS], float4 (&xb)[128 / KS]) {
+    if constexpr (KS == 16) ief_load_sc1<16>(x0, x1, s, true, xa, xb);
+    else {
+        const float *pa[4], *pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (32 * u + s);
+            const int off = ((k >> 3) * 16) * 8 + (k & 7);
+            pa[u] = x0 + off;
+            pb[u] = x1 + off;
+        }
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+            "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+            "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(xa[0]), "=&v"(xa[1]), "=&v"(xa[2]), "=&v"(xa[3]), "=&v"(xb[0]), "=&v"(xb[1]), "=&v"(xb[2]), "=&v"(xb[3])
+            : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3])
+            : "memory");
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ bool ief_load_poll(const float* x0, const float* x1, int s, float4 (&xa)[128 / KS], float4 (&xb)[128 / KS], unsigned int spin_limit) {
     unsigned int spins = 0;
     for (;;) {
-        ief_load_sc1<16>(x0, x1, s, true, xa, xb);
+        ief_load_sc1_ks<KS>(x0, x1, s, xa, xb);
         unsigned int m = 0xFFFFFFFFu;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 128 / KS; ++u) {
             m = min(m, min(__builtin_bit_cast(unsigned int, xa[u].x), __builtin_bit_cast(unsigned int, xa[u].y)));
             m = min(m, min(__builtin_bit_cast(unsigned int, xa[u].z), __builtin_bit_cast(unsigned int, xa[u].w)));
             m = min(m, min(__builtin_bit_cast(unsigned int, xb[u].x), __builtin_bit_cast(unsigned int, xb[u].y)));
@@ -301,36 +325,83 @@ __device__ __forceinline__ bool ief_load_poll(const float* x0, const float* x1, 
     }
 }
 
-// ief_product on a polled (negated) vector: the same FMAs in the same order, the stored sign undone by the source modifier
+// the sum over a PAIR of DPP rows (32 lanes), in every lane: v_permlane16_swap of the value with a COPY of itself (two registers:
+// swapping a register with itself exchanges its own rows) leaves rows 0 / 2 in one result and rows 1 / 3 in the other
+__device__ __forceinline__ float ief_row_pair_sum(float v) {
+    v = ief_row_sum(v);
+    float c = v;
+    // (as asm: with both operands the same value hipcc's builtin form added the first result to itself; the wait states between a
+    // VALU write and the swap's read are the asm's own)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(c));
+    return v + c;
+}
+
+// a product over K = 512 on a polled (negated) vector; KS lanes share it (k-slices), lanes s < 16 of the group end with
+// (neuron s & 7, player s >> 3); the stored sign is undone by the FMA's source modifier.  KS = 16: ief_product's FMAs in its order.
+template <int KS>
 __device__ __forceinline__ float ief_product_poll(const float* wl, const float* x0, const float* x1, int s, unsigned int spin_limit, bool& ok) {
-    float4 xa[8], xb[8];
-    ok &= ief_load_poll(x0, x1, s, xa, xb, spin_limit);
+    constexpr int U = 128 / KS;
+    float4 xa[U], xb[U];
+    ok &= ief_load_poll<KS>(x0, x1, s, xa, xb, spin_limit);
     float mine = 0.f;
+    const int sl = s & 15;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 w = *reinterpret_cast<const float4*>(wl + n * 512 + 4 * (16 * u + s));
+        for (int u = 0; u < U; ++u) {
+            const float4 w = *reinterpret_cast<const float4*>(wl + n * 512 + 4 * (KS * u + s));
             a0 = fmaf(w.x, -xa[u].x, a0); a0 = fmaf(w.y, -xa[u].y, a0); a0 = fmaf(w.z, -xa[u].z, a0); a0 = fmaf(w.w, -xa[u].w, a0);
             a1 = fmaf(w.x, -xb[u].x, a1); a1 = fmaf(w.y, -xb[u].y, a1); a1 = fmaf(w.z, -xb[u].z, a1); a1 = fmaf(w.w, -xb[u].w, a1);
         }
-        a0 = ief_row_sum(a0);
-        a1 = ief_row_sum(a1);
-        mine = s == n ? a0 : (s == n + 8 ? a1 : mine);
+        a0 = KS == 32 ? ief_row_pair_sum(a0) : ief_row_sum(a0);
+        a1 = KS == 32 ? ief_row_pair_sum(a1) : ief_row_sum(a1);
+        mine = sl == n ? a0 : (sl == n + 8 ? a1 : mine);
     }
     return mine;
 }
 
-__global__ __launch_bounds__(128) void ief_poll_kernel(const IefArgs a) {
+// the first product: the pooled features of the previous launch (plain rows, plain loads), KS lanes per player pair
+template <int KS>
+__device__ __forceinline__ float ief_product_feats(const float* wl, const float* x0, const float* x1, int s) {
+    if constexpr (KS == 16) return ief_product<16>(wl, x0, x1, s, false);
+    else {
+        float mine = 0.f;
+        float4 xa[4], xb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xa[u] = *reinterpret_cast<const float4*>(x0 + 4 * (32 * u + s));
+            xb[u] = *reinterpret_cast<const float4*>(x1 + 4 * (32 * u + s));
+        }
+        const int sl = s & 15;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 w = *reinterpret_cast<const float4*>(wl + n * 512 + 4 * (32 * u + s));
+                a0 = fmaf(w.x, xa[u].x, a0); a0 = fmaf(w.y, xa[u].y, a0); a0 = fmaf(w.z, xa[u].z, a0); a0 = fmaf(w.w, xa[u].w, a0);
+                a1 = fmaf(w.x, xb[u].x, a1); a1 = fmaf(w.y, xb[u].y, a1); a1 = fmaf(w.z, xb[u].z, a1); a1 = fmaf(w.w, xb[u].w, a1);
+            }
+            a0 = ief_row_pair_sum(a0);
+            a1 = ief_row_pair_sum(a1);
+            mine = sl == n ? a0 : (sl == n + 8 ? a1 : mine);
+        }
+        return mine;
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(8 * KS) void ief_poll_kernel(const IefArgs a) {
     extern __shared__ __align__(16) float ief_w[];           // [4][8][512]: W1f, W13, W2, W3 rows 8g..8g+7
-    constexpr int PPB = 16, NT = 128;
+    constexpr int PPB = 16, NT = 8 * KS;                     // eight player pairs x KS lanes
     const int t = threadIdx.x, g = blockIdx.x, pb = blockIdx.y;
-    const int s = t & 15, pair = t >> 4;
+    const int s = t % KS, pair = t / KS;
+    const bool owner = s < 16;                               // the lanes that own an output: (neuron s & 7, player s >> 3) of the pair
     const int bA = pb * PPB + 2 * pair, bB = bA + 1;
     const int n = 8 * g + (s & 7);
-    const int b = (s >> 3) ? bB : bA;
-    const bool live = b < a.B;
+    const int b = ((s >> 3) & 1) ? bB : bA;
+    const bool live = owner && b < a.B;
     const int rA = bA < a.B ? bA : a.B - 1, rB = bB < a.B ? bB : a.B - 1;
     {
         const float* src[4] = {a.w1f, a.w13, a.w2, a.w3};
@@ -347,11 +418,11 @@ __global__ __launch_bounds__(128) void ief_poll_kernel(const IefArgs a) {
     }
     __syncthreads();
     float* const hid = a.hid + (size_t)pb * (2 * a.iters) * kIefPhaseFloats;      // phase 2 it: h1 of iteration it; 2 it + 1: S after it
-    const int mine = g * NT + t;                                                   // [g][player][8]: thread t float t, a 128-byte line per wave-store
+    const int mine = g * 128 + 16 * pair + (s & 15);                               // [g][player][8]: a 128-byte line per wave-store
     const int pA = 2 * pair, pB = 2 * pair + 1;
     bool ok = true;
-    const float f1 = ief_product<PPB>(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s, false);
-    __hip_atomic_store(hid + mine, -fmaxf(f1 + a.cvec[n], 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float f1 = ief_product_feats<KS>(ief_w, a.feats + (size_t)rA * kFeat, a.feats + (size_t)rB * kFeat, s);
+    if (owner) __hip_atomic_store(hid + mine, -fmaxf(f1 + a.cvec[n], 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float ssum = 0.f;
     const float b2 = a.b2[n];
     for (int it = 0; it < a.iters; ++it) {
@@ -359,16 +430,16 @@ __global__ __launch_bounds__(128) void ief_poll_kernel(const IefArgs a) {
         float* const sp = h1p + kIefPhaseFloats;
         if (it > 0) {
             const float* const sprev = h1p - kIefPhaseFloats;
-            const float v = ief_product_poll(ief_w + 4096, sprev + pA * 8, sprev + pB * 8, s, a.spin_limit, ok);
-            __hip_atomic_store(h1p + mine, -fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v = ief_product_poll<KS>(ief_w + 4096, sprev + pA * 8, sprev + pB * 8, s, a.spin_limit, ok);
+            if (owner) __hip_atomic_store(h1p + mine, -fmaxf(f1 + a.cvec[it * kHid + n] + v, 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const float v = ief_product_poll(ief_w + 2 * 4096, h1p + pA * 8, h1p + pB * 8, s, a.spin_limit, ok);
+        const float v = ief_product_poll<KS>(ief_w + 2 * 4096, h1p + pA * 8, h1p + pB * 8, s, a.spin_limit, ok);
         ssum += fmaxf(b2 + v, 0.f);
-        __hip_atomic_store(sp + mine, -ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (owner) __hip_atomic_store(sp + mine, -ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (8 * g < kNPar) {
         const float* const slast = hid + (size_t)(2 * a.iters - 1) * kIefPhaseFloats;
-        float v = a.p0[n < kNPar ? n : 0] + ief_product_poll(ief_w + 3 * 4096, slast + pA * 8, slast + pB * 8, s, a.spin_limit, ok);
+        float v = a.p0[n < kNPar ? n : 0] + ief_product_poll<KS>(ief_w + 3 * 4096, slast + pA * 8, slast + pB * 8, s, a.spin_limit, ok);
         if (!ok) v = __builtin_nanf("");
         if (live && n < kNPar) {
             if (n < 3) a.cam[b * 3 + n] = v;
@@ -454,7 +525,7 @@ struct spsp_regressor {
     bool ief_counters_fresh = false;
     float* ief_hid = nullptr;           // the polling IEF's per-phase hand-off buffers (zeroed by every forward's stem kernel)
     size_t ief_hid_block = 0;           // floats per block of 16 players: 2 iters x 32 KB
-    int ief_poll = 1;                   // 1: ief_poll_kernel (the data is its own flag), 0: ief_fused_kernel (arrival counters; SPSP_DEBUG_IEF_POLL)
+    int ief_poll = 2;                   // 2: ief_poll_kernel<32> (the data is its own flag; 32 lanes per player pair), 1: <16> (ief_fused_kernel's sums bit for bit), 0: ief_fused_kernel (arrival counters; SPSP_DEBUG_IEF_POLL)
     int ief_block = 16;                 // players per IEF block (64 workgroups that hand off to each other): 32, or 16 = two independent halves
     ~spsp_regressor() { if (err_host) (void)hipHostFree(err_host); }
 };
@@ -662,8 +733,11 @@ int spsp_regressor_load(spsp_ctx* ctx, const spsp_regressor_weights* w, int max_
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ief_fused_kernel<32>, 256, kIefLds) != hipSuccess) per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_fused_kernel<16>, 128, kIefLds) != hipSuccess) per_cu16 = 0;
         if (per_cu16 < per_cu) per_cu = per_cu16;
-        TRY(ensure_dynamic_lds<&ief_poll_kernel>(kIefLds));
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_poll_kernel, 128, kIefLds) != hipSuccess) per_cu16 = 0;
+        TRY(ensure_dynamic_lds<&ief_poll_kernel<16>>(kIefLds));
+        TRY(ensure_dynamic_lds<&ief_poll_kernel<32>>(kIefLds));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_poll_kernel<16>, 128, kIefLds) != hipSuccess) per_cu16 = 0;
+        if (per_cu16 < per_cu) per_cu = per_cu16;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu16, ief_poll_kernel<32>, 256, kIefLds) != hipSuccess) per_cu16 = 0;
         if (per_cu16 < per_cu) per_cu = per_cu16;
         r->ief_capacity = per_cu * ctx->num_cus;
         if (w->ief_iters > 0 && r->ief_capacity < kIefG * SPSP_REGRESSOR_MAX_CONCURRENT) {
@@ -851,9 +925,11 @@ int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, floa
         }
         SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel<32>>(kIefLds));
         SPSP_TRY(ensure_dynamic_lds<&ief_fused_kernel<16>>(kIefLds));
-        SPSP_TRY(ensure_dynamic_lds<&ief_poll_kernel>(kIefLds));
+        SPSP_TRY(ensure_dynamic_lds<&ief_poll_kernel<16>>(kIefLds));
+        SPSP_TRY(ensure_dynamic_lds<&ief_poll_kernel<32>>(kIefLds));
         ProfScope ps(ctx, kKIefFc, st, true);
-        if (r->ief_poll) launch_kernel(&ief_poll_kernel, dim3(ief_wgs, (B + 15) / 16), dim3(128), kIefLds, st, ia);
+        if (r->ief_poll == 2) launch_kernel(&ief_poll_kernel<32>, dim3(ief_wgs, (B + 15) / 16), dim3(256), kIefLds, st, ia);
+        else if (r->ief_poll) launch_kernel(&ief_poll_kernel<16>, dim3(ief_wgs, (B + 15) / 16), dim3(128), kIefLds, st, ia);
         else if (ppb == 16) launch_kernel(&ief_fused_kernel<16>, dim3(ief_wgs, npb), dim3(128), kIefLds, st, ia);
         else launch_kernel(&ief_fused_kernel<32>, dim3(ief_wgs, npb), dim3(256), kIefLds, st, ia);
     } else {
@@ -906,7 +982,7 @@ int spsp_regressor_debug(spsp_regressor* r, int what, int value) {
             SPSP_REQUIRE(value == 16 || value == 32, "spsp_regressor_debug: IEF blocks of %d players (16 or 32)", value);
             r->ief_block = value;
             return SPSP_OK;
-        case SPSP_DEBUG_IEF_POLL: r->ief_poll = value != 0; return SPSP_OK;
+        case SPSP_DEBUG_IEF_POLL: if (value < 0 || value > 2) return SPSP_EINVAL; r->ief_poll = value; return SPSP_OK;
         case SPSP_DEBUG_PLAN_RS:
             SPSP_REQUIRE(value == 0 || (value >= 2 && value <= 512 && value % 2 == 0), "spsp_regressor_debug: conv_rs on %d workgroups (0: off; even)", value);
             r->rs_wgs = value;
