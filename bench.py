@@ -143,6 +143,7 @@ def rocprof_average_us(table_name, plan):
     for row in csv.DictReader(open(path)):
         name = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
         name = re.sub(r'^conv1_pool32r?_kernel', 'conv1_pool_kernel', name)        # the stem's forms are one table row
+        name = re.sub(r'^ief_poll_kernel<\d+>', 'ief_fused_kernel', name)          # ... and the IEF's
         if name.startswith(want) and (not targs or name[len(want)] in ',>'):
             calls += float(row['Calls'])
             tot += float(row['TotalDurationUs'])

@@ -49,6 +49,8 @@ def to_library_name(rocprof_name, names):
     longest matching argument prefix."""
     base, args = split_template(short(rocprof_name))
     base = re.sub(r'^conv1_pool32r?_kernel$', 'conv1_pool_kernel', base)          # the stem's forms are one table row
+    if base == 'ief_poll_kernel':                                                  # ... and the IEF's
+        base, args = 'ief_fused_kernel', []
     best = None
     for n in names:
         nb, na = split_template(n)
