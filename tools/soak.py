@@ -1,6 +1,6 @@
 """Soak: N steps of the four-slot pipeline (plan "throughput", HIP graphs, eight rotating input batches); EVERY result is compared
 bit for bit with the serial path's result for its input (checked three submits later, before its slot's buffers are reused).
-usage: python tools/soak.py [steps]"""
+usage: python tools/soak.py [steps] [players per batch]"""
 import os
 import sys
 import time
@@ -16,7 +16,7 @@ from soccerplayershapepose_amd.models.smpl_official import SMPL  # noqa: E402
 from soccerplayershapepose_amd.player_recon import PlayerPipeline, reconstruct_players  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-B, NIN, depth = 32, 8, 4
+B, NIN, depth = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 8, 4
 dev = torch.device('cuda', 0)
 sd, model = S.regressor_state_dict(seed=0), S.smpl_model(seed=0)
 mk_r = lambda: SingleInputRegressor(18, 18, 3, mean_params=S.mean_params(), max_batch=B, precision='f16').load_state_dict(sd).to(dev)
