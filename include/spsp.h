@@ -181,15 +181,17 @@ int spsp_regressor_forward(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, 
  *   ief:      the iterative-error-feedback MLP on rows [0, B) of that buffer -> cam / pose6d / betas (feats optional).
  * Several backbone calls with different feat_row, then ONE ief over all their rows: how spsp_pipeline_group batches the
  * latency-bound tail of the path (IEF -> fit -> SMPL) over consecutive batches while the convolutions keep their batch.
- * The fused IEF kernel's grid-wide hand-offs count on eight monotonic counters of the handle that must start at zero: a backbone
- * call leaves them zeroed (its stem kernel does it), an ief call uses them up.  spsp_regressor_ief tracks that on the handle (host
- * side) and, when no backbone call has run since the last ief -- ief twice on the same features, ief on a fresh handle -- zeroes
- * them itself with a memset on `stream` first; both orders give the same results.  (Under stream capture the choice is made when
+ * The fused IEF kernel's grid-wide hand-offs rely on state of the handle that must start as zeros: the per-phase hand-off buffers a
+ * consumer polls until its words are non-zero (round 5; 2 x iterations x 32 KB per 16 players) and, in the arrival-counter forms, eight
+ * monotonic counters.  A backbone call leaves both zeroed for the rows it covers (its stem kernel does it, every workgroup a share), an
+ * ief call uses them up.  spsp_regressor_ief tracks that on the handle (host side) and, when no backbone call has run since the last
+ * ief -- ief twice on the same features, ief on a fresh handle -- zeroes them itself with memsets on `stream` first; both orders give
+ * the same results.  (Under stream capture the choice is made when
  * the call is captured: capture backbone + ief together, or an ief alone that is preceded by a backbone call at capture time
  * only if every replay is.) */
 int spsp_regressor_backbone(spsp_ctx* ctx, spsp_regressor* r, const void* proxy, int proxy_format, int B, int feat_row, void* stream);
 int spsp_regressor_ief(spsp_ctx* ctx, spsp_regressor* r, int B, float* cam, float* pose6d, float* betas, float* feats, void* stream);
-/* Launch plan of the handle's forwards (same results up to the fp32 summation order of layer3; takes effect at the next forward,
+/* Launch plan of the handle's forwards (same results up to the fp32 summation order of layer2 and layer3; takes effect at the next forward,
  * not inside a captured graph).
  * SPSP_PLAN_LATENCY (a fresh handle's plan): for ONE batch in flight -- every kernel's grid fills the chip.
  * SPSP_PLAN_THROUGHPUT: for several batches in flight on different streams (four pipeline slots) -- the kernels with the least CU
